@@ -1,0 +1,161 @@
+"""Pins the CPU oracle (oracle/sinddm_oracle.py) to outputs of the reference itself
+(fixtures produced by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2, max_abs
+from oracle import sinddm_oracle as O
+from sinddm_amd.synth import closed_form_state_dict, closed_form_tensor, hash_randn, noise_key
+
+
+def _sched(meta, name, T=None):
+    c = meta[name]
+    return O.make_schedule(T or c["T"], c["n_scales"], c["rescale_losses"], 1, train_full_t=True)
+
+
+def test_g1_schedule_bit_exact(golden):
+    meta = golden("g11_img_scales.json")
+    g1 = golden("g1_schedule.npz")
+    for name in ("C1", "C2", "C3", "C4", "C5"):
+        s = _sched(meta, name)
+        assert s["num_timesteps_ideal"] == meta[name]["num_timesteps_ideal"]
+        assert s["num_timesteps_trained"] == meta[name]["num_timesteps_trained"]
+        assert np.array_equal(s["gammas"].numpy(), g1[f"{name}_gammas"])
+    for name, T in (("C1", 100), ("C2", 1000)):
+        s = _sched(meta, name)
+        for b in O.SCHEDULE_BUFFERS:
+            assert np.array_equal(s[b].numpy(), g1[f"T{T}_{b}"]), b
+
+
+def test_g2_posemb(golden):
+    g = golden("g2_posemb.npz")
+    assert max_abs(O.sinusoidal_emb(torch.arange(1000)), g["t_emb"]) == 0.0
+    assert max_abs(O.sinusoidal_emb(torch.arange(6, dtype=torch.float32)), g["s_emb"]) == 0.0
+
+
+@pytest.mark.parametrize("dim,H,W", [(160, 37, 41), (32, 67, 90), (160, 24, 50)])
+def test_g3_net_forward(golden, dim, H, W):
+    g = golden("g3_net.npz")
+    sd = closed_form_state_dict(dim)
+    x = closed_form_tensor((2, 3, H, W), phase=0.3, amp=1.2)
+    t = torch.tensor([17, 3])
+    for s in (0, 2):
+        y = O.net_forward(sd, x, t, s)
+        assert rel_l2(y, g[f"d{dim}_{H}x{W}_s{s}"]) < 2e-6
+
+
+def test_g3_cond_vec(golden):
+    g = golden("g3_net.npz")
+    sd = closed_form_state_dict(160)
+    c = O.cond_vector(sd, torch.tensor([0, 1, 17, 99, 999]), 3)
+    assert max_abs(c, g["cond_vec_s3"]) < 1e-6
+
+
+def test_g4_block_forward(golden):
+    g = golden("g4_block.npz")
+    sd = closed_form_state_dict(32)
+    cond = closed_form_tensor((2, 32), phase=1.0, amp=0.7)
+    for name, (cin, cout) in zip(("l1", "l2", "l3", "l4"), O.block_channels(32)):
+        x = closed_form_tensor((2, cin, 24, 20), phase=0.11 * cin, amp=0.9)
+        y = O.conv_block(sd, name, x, cond)
+        assert rel_l2(y, g[f"{name}_y"]) < 2e-6
+
+
+def test_g4_g5_grads_via_autograd(golden):
+    """The oracle is differentiable torch code; its autograd grads must match the reference's."""
+    meta = golden("g11_img_scales.json")
+    g5 = golden("g5_losses.npz")
+    pyr = golden("c1_pyramid.npz")
+    sched = _sched(meta, "C1")
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)
+    for s in (0, 2):
+        sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(32).items()}
+        orig = to_t(pyr[f"scale_{s}"])[None].repeat(2, 1, 1, 1)
+        recon = to_t(pyr[f"scale_{s}_recon"])[None].repeat(2, 1, 1, 1) if s > 0 else orig
+        t = torch.tensor([37, 5])
+        noise = hash_randn(tuple(orig.shape), noise_key("train", s, 0))
+        loss = O.p_losses(sched, sd, recon if s > 0 else orig, t, s, noise, x_orig=orig if s > 0 else None)
+        loss.backward()
+        assert abs(float(loss) - float(g5[f"s{s}_loss"])) < 1e-6
+        for k, v in sd.items():
+            assert rel_l2(v.grad, g5[f"s{s}_g_{k}"]) < 5e-5, k
+
+
+def test_g6_p_sample(golden):
+    meta = golden("g11_img_scales.json")
+    g = golden("g6_psample.npz")
+    sched = _sched(meta, "C1")
+    sd = closed_form_state_dict(32)
+    for s, (H, W) in ((0, (48, 64)), (2, (94, 126))):
+        for t in (17, 1, 0):
+            x = closed_form_tensor((2, 3, H, W), phase=0.5 + t, amp=1.1)
+            xt = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211)
+            z = hash_randn((2, 3, H, W), noise_key("step", s, t))
+            # reverse step alone, fed the reference's own eps: must be (near) exact
+            y = O.reverse_step(sched, x, torch.from_numpy(g[f"eps_s{s}_t{t}"]), t, s, z, xt)
+            assert max_abs(y, g[f"psample_s{s}_t{t}"]) <= 1e-6, (s, t)
+            y2 = O.p_sample(sched, sd, x, t, s, z, xt)
+            assert rel_l2(y2, g[f"psample_s{s}_t{t}"]) < 1e-5, (s, t)
+
+
+def test_g7_q_sample(golden):
+    meta = golden("g11_img_scales.json")
+    sched = _sched(meta, "C1")
+    x0 = closed_form_tensor((3, 3, 20, 30), phase=0.2)
+    nz = hash_randn((3, 3, 20, 30), 77)
+    y = O.q_sample(sched, x0, torch.tensor([0, 41, 99]), nz)
+    assert max_abs(y, golden("g7_qsample.npz")["y"]) == 0.0
+
+
+def test_g8_bilinear(golden):
+    g = golden("g8_bilinear.npz")
+    for (h, w), (H, W), C in (((48, 64), (67, 90), 3), ((133, 177), (186, 248), 1), ((46, 69), (92, 276), 2),
+                              ((67, 90), (94, 126), 3)):
+        x = closed_form_tensor((1, C, h, w), phase=0.9, amp=1.0, freq=0.271)
+        y = O.bilinear_upsample(x, (H, W))
+        assert max_abs(y, g[f"{h}x{w}_to_{H}x{W}"]) < 2e-6
+
+
+def test_g9_chain_c1(golden):
+    """Full 3-scale C1 chain (193 net evals at dim=160) with hash noise: index bookkeeping
+    bit-exact, images within 1e-4 rel-L2 (the north_star tolerance)."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g9_chain_c1.npz")
+    c1 = meta["C1"]
+    sched = _sched(meta, "C1")
+    assert sched["num_timesteps_ideal"] == list(g["ideal"])
+    sd = closed_form_state_dict(160)
+    sizes = [tuple(s) for s in c1["image_sizes_hw"]]
+
+    class Noise(dict):
+        def __missing__(self, k):
+            kind, s = k[0], k[1]
+            t = k[2] if len(k) > 2 else 0
+            H, W = sizes[s]
+            return hash_randn((1, 3, H, W), noise_key(kind, s, t))
+
+    trace = []
+    with torch.no_grad():
+        outs = O.sample_chain(sched, sd, sizes, Noise(), 1, trace=trace)
+    assert sum(len(t[2]) for t in trace) + len(trace) == int(g["plan_len"])
+    for i, o in enumerate(outs):
+        assert rel_l2(o, g[f"out_s{i}"]) < 1e-4, i
+
+
+def test_adam_and_lr_restatement():
+    torch.manual_seed(0)
+    p = torch.randn(50)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2, 4], gamma=0.5)
+    m, v = torch.zeros(50), torch.zeros(50)
+    for n in range(1, 7):
+        g = torch.randn(50)
+        ref.grad = g.clone()
+        lr = O.multistep_lr(1e-3, [2, 4], n)
+        assert abs(lr - opt.param_groups[0]["lr"]) < 1e-12
+        opt.step()
+        sch.step()
+        O.adam_step(p, g, m, v, n, lr)
+        assert max_abs(p, ref.detach()) < 1e-7
