@@ -1,0 +1,111 @@
+/*
+ * sinddm_hip.h -- C ABI of the MI355X (gfx950) SinDDM hot-path library (libsinddm_hip.so).
+ *
+ * Drop-in boundary: the reference is pure Python/PyTorch, so the
+ * "FFI" a maintainer binds is ctypes.  Each entry point below replaces a chain of
+ * PyTorch library calls in the reference; the file:line it replaces is cited.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
+ *     (PyTorch-ROCm tensors) unless marked "host"; the library never allocates or
+ *     frees device memory and keeps no mutable global state (the opt-in
+ *     sinddm_prof_* measurement hooks at the end are the only exception).
+ *   - all tensors are fp32, NCHW, contiguous.  Timesteps are int64.
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no
+ *     host synchronisation inside.  Re-entrant across streams.
+ *   - return value: 0 = ok; >0 = hipError_t from a launch; <0 = SINDDM_E_* below.
+ */
+#ifndef SINDDM_HIP_H
+#define SINDDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SINDDM_ABI_VERSION 1
+
+#define SINDDM_E_BADARG   (-1)  /* null pointer / non-positive size            */
+#define SINDDM_E_BADSHAPE (-2)  /* dim/channels not supported by the kernels   */
+#define SINDDM_E_WORKSPACE (-3) /* workspace too small (see *_workspace_bytes) */
+
+/* ---- introspection --------------------------------------------------------------------- */
+int sinddm_abi_version(void);
+
+/* Number of fp32 elements of the flat parameter buffer of SinDDMNet(dim, channels=3,
+ * multiscale=True) in nn.Module registration order (reference SinDDM/models.py:100-132;
+ * key list in SURVEY.md 8(b)), and the offset of the idx-th tensor (0..n_tensors-1). */
+int64_t sinddm_param_count(int dim);
+int sinddm_param_tensors(int dim);
+int64_t sinddm_param_offset(int dim, int idx);
+
+/* Number of fp32 elements of the MFMA-ready packed weight image built by sinddm_pack_weights. */
+int64_t sinddm_packed_count(int dim);
+
+/* Bytes of scratch sinddm_net_forward needs for a (B,3,H,W) input. */
+size_t sinddm_workspace_bytes(int dim, int B, int H, int W);
+
+/* ---- network ---------------------------------------------------------------------------- */
+/* Re-layout the 3x3 / 1x1 conv weights of the flat parameter buffer into the chunked
+ * [co-block][ci-chunk][tap][ci][co] image the MFMA kernels stage into LDS.  Must be called
+ * after every parameter update (load_state_dict, optimizer step). */
+int sinddm_pack_weights(const float* params, float* packed, int dim, void* stream);
+
+/* eps = SinDDMNet.forward(x, t, scale)          reference SinDDM/models.py:134-151
+ *   params  flat parameter buffer (sinddm_param_count floats)
+ *   packed  image made by sinddm_pack_weights from the same params
+ *   x       (B,3,H,W)     t_dev (B,) int64 or NULL -> every sample uses t_host
+ *   scale   the pyramid scale s (python int / 1-elem tensor in the reference, models.py:137)
+ *   out     (B,3,H,W)     ws/ws_bytes scratch >= sinddm_workspace_bytes()               */
+int sinddm_net_forward(const float* params, const float* packed, const float* x,
+                       const int64_t* t_dev, int t_host, float scale, float* out,
+                       int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- diffusion elementwise --------------------------------------------------------------- */
+/* out = sqrt_ac[t]*x0 + sqrt_1m_ac[t]*noise      reference SinDDM/models.py:570-576 (+extract,
+ * functions.py:105-108).  If x_orig != NULL the training-time blur mix of models.py:583-585 is
+ * fused in front:  x0 := gamma_row[t]*x0 + (1-gamma_row[t])*x_orig.
+ * t_dev (B,) int64 or NULL -> t_host for all samples.  n = C*H*W elements per sample.        */
+int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, float* out,
+                    const float* tab_sqrt_ac, const float* tab_sqrt_1m_ac, const float* gamma_row,
+                    const int64_t* t_dev, int t_host, int B, int64_t n, void* stream);
+
+/* Per-step scalars of one reverse diffusion step (all samples share t, models.py:481,541). */
+typedef struct sinddm_step_coefs {
+    int mode;            /* 0: s==0 or !reblurring (DDPM posterior, models.py:322-330)
+                            1: s>0, t>0  (re-blur mix, models.py:331-345,434-436)
+                            2: s>0, t==0 (models.py:347-350)                                */
+    int clip;            /* clip_denoised (models.py:440-442) */
+    float sqrt_recip_ac_t, sqrt_recipm1_ac_t;      /* models.py:308-309 */
+    float coef1_t, coef2_t;                        /* mode 0: posterior_mean_coef1/2 */
+    float gamma_t, gamma_tm1;                      /* clamp(gammas[s-1],0,0.55)[t], [t-1] */
+    float sqrt_ac_tm1, sqrt_ac_t, sqrt_1m_ac_t;    /* mode 1 */
+    float sqrt_1m_ac_tm1_mvar;                     /* sqrt(1 - ac[t-1] - var)  (models.py:343) */
+    float sigma;                                   /* [t!=0]*exp(0.5*logvar)   (models.py:459) */
+} sinddm_step_coefs;
+
+/* x_{t-1} = p_sample tail: predict_start_from_noise + p_mean_variance(normal branch) +
+ * q_posterior + noise add.   reference SinDDM/models.py:306-352,433-459.
+ * x_tilde = img_prev_upsample (NULL in mode 0).  n = total elements B*C*H*W.                 */
+int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde,
+                        const float* noise, float* out, const sinddm_step_coefs* coefs /*host*/,
+                        int64_t n, void* stream);
+
+/* F.interpolate(in, size=(H,W), mode='bilinear') (align_corners=False)  models.py:567 */
+int sinddm_upsample_bilinear(const float* in, float* out, int BC, int h, int w, int H, int W,
+                             void* stream);
+
+/* ---- measurement hooks (bench.py roofline leg) ----------------------------------------------
+ * Between prof_begin and prof_end every MFMA conv launch is bracketed by hipEvents on the stream it
+ * is launched on; prof_end synchronises those events and returns the summed kernel time (ms), the
+ * number of launches and their algorithmic FLOPs (2*B*H*W*Cout*(9*Cin + Cin2)).  Process-global,
+ * not thread-safe; off by default.  No reference counterpart (the reference has no profiling). */
+int sinddm_prof_begin(void);
+int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SINDDM_HIP_H */

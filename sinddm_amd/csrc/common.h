@@ -1,0 +1,42 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "plan.h"
+#include "../../include/sinddm_hip.h"
+
+namespace sinddm {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+#define SINDDM_LAUNCH_CHECK()                          \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)
+
+__device__ __forceinline__ float gelu_erf(float v) {
+    // exact-erf GELU (nn.GELU() default), reference SinDDM/models.py:55,64,108
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float gelu_erf_grad(float v) {
+    // d/dv [0.5 v (1+erf(v/sqrt2))] = 0.5(1+erf(v/sqrt2)) + v * exp(-v^2/2)/sqrt(2 pi)
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
+
+// ---- geometry of the implicit-GEMM 3x3 conv tile (shared by forward / dgrad) ----
+constexpr int CONV_THREADS = 256;   // 4 waves, one per SIMD; 2-3 workgroups per CU
+constexpr int CONV_NT = 4;          // 16-pixel N tiles per wave
+constexpr int CONV_WN = 4;          // waves along N
+constexpr int CONV_TW = 32;         // tile width  (pixels)
+constexpr int CONV_TPR = CONV_TW / 16;                       // N tiles per tile row
+constexpr int CONV_TH = CONV_WN * CONV_NT / CONV_TPR;        // tile height = 8
+constexpr int CONV_RS = CONV_TW + 2;                         // LDS row stride incl. halo
+constexpr int CONV_HR = CONV_TH + 2;                         // LDS rows incl. halo
+constexpr int CONV_PS = ((CONV_HR * CONV_RS - 16 + 31) / 32) * 32 + 16;  // plane stride == 16 mod 32
+constexpr int CONV_IN_ELEMS = KC * CONV_HR * CONV_RS;
+constexpr int CONV_IREGS = (CONV_IN_ELEMS + CONV_THREADS - 1) / CONV_THREADS;
+
+}  // namespace sinddm

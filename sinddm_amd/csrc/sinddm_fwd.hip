@@ -1,0 +1,523 @@
+// Forward path of the SinDDM hot path for gfx950: weight packing, conditioning MLP, depthwise
+// 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
+#include "conv_mfma.h"
+
+namespace sinddm {
+
+ConvProfiler& conv_profiler() {
+    static ConvProfiler p;
+    return p;
+}
+
+// =====================================================================================
+// weight packing: flat nn.Module-order parameters -> MFMA chunk images
+// =====================================================================================
+struct PackSeg {
+    long long dst;     // offset in packed
+    long long count;   // elements in this segment
+    long long w;       // source weight offset (conv: [cout][cin][taps]), or bias offset
+    long long w2;      // second bias offset to add (-1 none)
+    int kind;          // 0: conv chunks, 1: bias
+    int cin, cout, taps, nch, mt, co_lds;
+    int transpose;     // 1: dgrad image (M = cin of the forward conv, taps flipped)
+};
+struct PackArgs {
+    PackSeg seg[24];
+    int nseg;
+    long long total;
+};
+
+__global__ void pack_kernel(const float* __restrict__ params, float* __restrict__ packed, PackArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    int s = 0;
+    long long base = 0;
+    while (s < a.nseg - 1 && i >= base + a.seg[s].count) { base += a.seg[s].count; ++s; }
+    const PackSeg& g = a.seg[s];
+    const long long j = i - base;
+    float v = 0.0f;
+    if (g.kind == 0) {
+        // [coblk][chunk][tap][kc][co_lds]
+        const int co_l = (int)(j % g.co_lds);
+        long long r = j / g.co_lds;
+        const int kc = (int)(r % KC); r /= KC;
+        const int tap = (int)(r % g.taps); r /= g.taps;
+        const int ch = (int)(r % g.nch); r /= g.nch;
+        const int cb = (int)r;
+        const int m = cb * g.mt * 16 + co_l;      // GEMM row (output channel of THIS conv)
+        const int k = ch * KC + kc;               // GEMM k channel (input channel of THIS conv)
+        if (!g.transpose) {
+            if (co_l < g.mt * 16 && m < g.cout && k < g.cin)
+                v = params[g.w + ((long long)m * g.cin + k) * g.taps + tap];
+        } else {
+            // data-gradient image: this conv maps forward-cout channels (k) to forward-cin channels (m)
+            // with spatially flipped taps:  W'[m][k][tap] = W[k][m][taps-1-tap]
+            if (co_l < g.mt * 16 && m < g.cin && k < g.cout)
+                v = params[g.w + ((long long)k * g.cin + m) * g.taps + (g.taps - 1 - tap)];
+        }
+    } else {
+        if (j < g.cout) {
+            v = params[g.w + j];
+            if (g.w2 >= 0) v += params[g.w2 + j];
+        }
+    }
+    packed[g.dst + j] = v;
+}
+
+static int pack_forward(const NetPlan& P, const float* params, float* packed, hipStream_t st) {
+    PackArgs a{};
+    int n = 0;
+    long long total = 0;
+    auto add = [&](PackSeg s) { a.seg[n++] = s; total += s.count; };
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        PackSeg s{};
+        s.kind = 0; s.mt = b.mt; s.co_lds = b.co_lds; s.transpose = 0; s.w2 = -1;
+        // conv1: cin -> cout, 3x3
+        s.dst = b.pk_c1; s.count = (long long)b.coblks * b.nch1 * 9 * KC * b.co_lds;
+        s.w = b.c1_w; s.cin = b.cin; s.cout = b.cout; s.taps = 9; s.nch = b.nch1;
+        add(s);
+        // conv2: cout -> cout, 3x3
+        s.dst = b.pk_c2; s.count = (long long)b.coblks * b.nch2 * 9 * KC * b.co_lds;
+        s.w = b.c2_w; s.cin = b.cout; s.cout = b.cout; s.taps = 9; s.nch = b.nch2;
+        add(s);
+        if (b.nchr > 0) {
+            s.dst = b.pk_res; s.count = (long long)b.coblks * b.nchr * KC * b.co_lds;
+            s.w = b.res_w; s.cin = b.cin; s.cout = b.cout; s.taps = 1; s.nch = b.nchr;
+            add(s);
+        }
+        PackSeg t{};
+        t.kind = 1; t.cout = b.cout; t.count = (long long)b.coblks * b.mt * 16;
+        t.dst = b.pk_b1; t.w = b.c1_b; t.w2 = -1;
+        add(t);
+        t.dst = b.pk_b2; t.w = b.c2_b; t.w2 = b.res_b;
+        add(t);
+    }
+    a.nseg = n;
+    a.total = total;
+    const int threads = 256;
+    const unsigned grid = (unsigned)((total + threads - 1) / threads);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(threads), 0, st, params, packed, a);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================
+// conditioning: sinusoidal embeddings -> time_mlp -> per-block (mlp, time_reshape)
+// reference SinDDM/models.py:39-46,106-110,136-141 and :54-60,74-76
+// =====================================================================================
+struct CondArgs {
+    const float* params;
+    const long long* t_dev;
+    int t_host;
+    float scale;
+    float* out;          // [B][cond_stride]
+    int cond_stride;
+    long long tm0_w, tm0_b, tm2_w, tm2_b;
+    long long mlp_w[4], mlp_b[4], tr_w[4], tr_b[4];
+    int cin[4], coff[4];
+    float* cond_vec;     // optional [B][32] raw cond vector (saved for backward), may be null
+    float* hidden;       // optional [B][128] pre-GELU hidden of time_mlp (saved for backward)
+};
+
+__global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
+    __shared__ float emb[64];
+    __shared__ float h1[128];
+    __shared__ float cv[32];
+    __shared__ float gv[32];
+    __shared__ float mv[32];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* P = a.params;
+    const float tval = a.t_dev ? (float)a.t_dev[b] : (float)a.t_host;
+    if (tid < 32) {
+        // f_i = exp(i * -(ln 1e4 / 15)): torch.exp(arange(16) * -emb) on CPU returns the correctly
+        // rounded fp32 exp of the fp32 argument; a double-precision exp rounded to fp32 reproduces it.
+        const int i = tid & 15;
+        const float f = (float)exp((double)((float)i * -0.6140226914650789f));  // ln(10000)/15
+        const float x = (tid < 16) ? tval : a.scale;
+        const float arg = x * f;
+        const int o = (tid < 16) ? 0 : 32;
+        emb[o + i] = sinf(arg);
+        emb[o + 16 + i] = cosf(arg);
+    }
+    __syncthreads();
+    {
+        float s = P[a.tm0_b + tid];
+        const float* w = P + a.tm0_w + (long long)tid * 64;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) s = fmaf(w[k], emb[k], s);
+        if (a.hidden) a.hidden[(long long)b * 128 + tid] = s;
+        h1[tid] = gelu_erf(s);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = P[a.tm2_b + tid];
+        const float* w = P + a.tm2_w + (long long)tid * 128;
+#pragma unroll 8
+        for (int k = 0; k < 128; ++k) s = fmaf(w[k], h1[k], s);
+        cv[tid] = s;
+        gv[tid] = gelu_erf(s);
+        if (a.cond_vec) a.cond_vec[(long long)b * 32 + tid] = s;
+    }
+    __syncthreads();
+    for (int l = 0; l < 4; ++l) {
+        if (tid < 32) {
+            float s = P[a.mlp_b[l] + tid];
+            const float* w = P + a.mlp_w[l] + (long long)tid * 32;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) s = fmaf(w[k], gv[k], s);
+            mv[tid] = s;
+        }
+        __syncthreads();
+        for (int c = tid; c < a.cin[l]; c += blockDim.x) {
+            float s = P[a.tr_b[l] + c];
+            const float* w = P + a.tr_w[l] + (long long)c * 32;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) s = fmaf(w[k], mv[k], s);
+            a.out[(long long)b * a.cond_stride + a.coff[l] + c] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================
+// depthwise 5x5 + bias + per-sample condition      reference SinDDM/models.py:61,70,77
+// HBM-bound: 8 B per (channel,pixel).  Tile 16x64 staged with its 2-pixel halo in LDS,
+// each thread produces a 1x4 output strip from 5 rows x 8 floats (two b128 reads per row).
+// =====================================================================================
+constexpr int DW_TH = 16, DW_TW = 64, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
+
+__global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, const float* __restrict__ cond,
+                                                       int cond_stride, float* __restrict__ out, int C, int H, int W,
+                                                       int tilesX) {
+    __shared__ __attribute__((aligned(16))) float tile[DW_HR * DW_RS];
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
+    const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+    const float* src = x + ((size_t)b * C + c) * H * W;
+    for (int i = threadIdx.x; i < DW_HR * DW_RS; i += 256) {
+        const int r = i / DW_RS, cc = i - r * DW_RS;
+        const int gy = y0 + r - 2, gx = x0 + cc - 2;
+        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+    }
+    float wk[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + k];
+    const float add = bias[c] + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
+    __syncthreads();
+    const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    float o0 = add, o1 = add, o2 = add, o3 = add;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy) {
+        const float4 lo = *reinterpret_cast<const float4*>(&tile[(r + dy) * DW_RS + xg * 4]);
+        const float4 hi = *reinterpret_cast<const float4*>(&tile[(r + dy) * DW_RS + xg * 4 + 4]);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+            const float wv = wk[dy * 5 + dx];
+            o0 = fmaf(wv, v[dx], o0);
+            o1 = fmaf(wv, v[dx + 1], o1);
+            o2 = fmaf(wv, v[dx + 2], o2);
+            o3 = fmaf(wv, v[dx + 3], o3);
+        }
+    }
+    const int gy = y0 + r;
+    if (gy < H) {
+        float* dst = out + (((size_t)b * C + c) * H + gy) * W;
+        const int gx = x0 + xg * 4;
+        if (gx < W) dst[gx] = o0;
+        if (gx + 1 < W) dst[gx + 1] = o1;
+        if (gx + 2 < W) dst[gx + 2] = o2;
+        if (gx + 3 < W) dst[gx + 3] = o3;
+    }
+}
+
+int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride, float* out,
+                  int B, int C, int H, int W, hipStream_t st) {
+    const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
+    hipLaunchKernelGGL(dwconv5_kernel, dim3(tilesX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
+                       out, C, H, W, tilesX);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================
+// final 1x1 conv (half -> 3)                      reference SinDDM/models.py:130-132,151
+// =====================================================================================
+__global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int C, int HW) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* src = a + (size_t)b * C * HW + p;
+    float o0 = bias[0], o1 = bias[1], o2 = bias[2];
+    for (int c = 0; c < C; ++c) {
+        const float v = src[(size_t)c * HW];
+        o0 = fmaf(w[c], v, o0);
+        o1 = fmaf(w[C + c], v, o1);
+        o2 = fmaf(w[2 * C + c], v, o2);
+    }
+    float* dst = out + (size_t)b * 3 * HW + p;
+    dst[0] = o0;
+    dst[HW] = o1;
+    dst[2 * (size_t)HW] = o2;
+}
+
+// =====================================================================================
+// diffusion elementwise kernels (HBM-bound)
+// =====================================================================================
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ xo,
+                                                       const float* __restrict__ nz, float* __restrict__ out,
+                                                       const float* __restrict__ tabA, const float* __restrict__ tabB,
+                                                       const float* __restrict__ gam, const long long* __restrict__ t_dev,
+                                                       int t_host, long long n) {
+    const int b = blockIdx.y;
+    const long long t = t_dev ? t_dev[b] : (long long)t_host;
+    const float ca = tabA[t], cb = tabB[t];
+    const float g = (xo != nullptr) ? gam[t] : 0.0f;
+    const size_t base = (size_t)b * n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = x0[base + i];
+        if (xo) v = g * v + (1.0f - g) * xo[base + i];   // models.py:584-585
+        out[base + i] = ca * v + cb * nz[base + i];      // models.py:574-575
+    }
+}
+
+__global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restrict__ xt, const float* __restrict__ eps,
+                                                           const float* __restrict__ xtil, const float* __restrict__ z,
+                                                           float* __restrict__ out, sinddm_step_coefs k, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = xt[i];
+        const float x0 = k.sqrt_recip_ac_t * x - k.sqrt_recipm1_ac_t * eps[i];   // models.py:308-309
+        float mean;
+        if (k.mode == 0) {
+            const float x0c = k.clip ? fminf(fmaxf(x0, -1.0f), 1.0f) : x0;
+            mean = k.coef1_t * x0c + k.coef2_t * x;                               // models.py:324-327
+        } else {
+            const float xb = xtil[i];
+            float xp = (x0 - k.gamma_t * xb) / (1.0f - k.gamma_t);                // models.py:315-316
+            if (k.mode == 1) {
+                float mix = k.gamma_tm1 * xb + (1.0f - k.gamma_tm1) * xp;         // models.py:435-436
+                float x0c = x0;
+                if (k.clip) {
+                    mix = fminf(fmaxf(mix, -1.0f), 1.0f);
+                    x0c = fminf(fmaxf(x0, -1.0f), 1.0f);
+                }
+                mean = k.sqrt_ac_tm1 * mix + k.sqrt_1m_ac_tm1_mvar * (x - k.sqrt_ac_t * x0c) / k.sqrt_1m_ac_t;  // :342-345
+            } else {
+                mean = k.clip ? fminf(fmaxf(xp, -1.0f), 1.0f) : xp;               // models.py:347-348
+            }
+        }
+        out[i] = mean + k.sigma * z[i];                                           // models.py:459
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int h, int w, int H, int W, float sy, float sx) {
+    const int bc = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int oy = p / W, ox = p - oy * W;
+    // ATen area_pixel_compute_source_index(align_corners=False): max(scale*(dst+0.5)-0.5, 0), fp32
+    float fy = sy * ((float)oy + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    float fx = sx * ((float)ox + 0.5f) - 0.5f;
+    fx = fx < 0.0f ? 0.0f : fx;
+    int iy0 = (int)fy; if (iy0 > h - 1) iy0 = h - 1;
+    int ix0 = (int)fx; if (ix0 > w - 1) ix0 = w - 1;
+    const int iy1 = iy0 + 1 < h ? iy0 + 1 : h - 1;
+    const int ix1 = ix0 + 1 < w ? ix0 + 1 : w - 1;
+    const float ly = fy - (float)iy0, lx = fx - (float)ix0;
+    const float* s = in + (size_t)bc * h * w;
+    const float tl = s[iy0 * w + ix0], tr = s[iy0 * w + ix1], bl = s[iy1 * w + ix0], br = s[iy1 * w + ix1];
+    out[(size_t)bc * H * W + p] = (1.0f - ly) * ((1.0f - lx) * tl + lx * tr) + ly * ((1.0f - lx) * bl + lx * br);
+}
+
+// =====================================================================================
+// whole-network forward orchestration
+// =====================================================================================
+struct FwdBuffers {
+    float* cond;    // [B][cond_stride]
+    float* buf[4];  // each B*dim*H*W
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
+    const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
+    const size_t cond = align_up((size_t)B * P.cond_stride * sizeof(float), 256);
+    return cond + 4 * act;
+}
+
+int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
+                     int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
+    if (ws_bytes < fwd_workspace_bytes(P, B, H, W)) return SINDDM_E_WORKSPACE;
+    char* base = static_cast<char*>(ws);
+    FwdBuffers fb;
+    fb.cond = reinterpret_cast<float*>(base);
+    base += align_up((size_t)B * P.cond_stride * sizeof(float), 256);
+    const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
+    for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
+
+    CondArgs ca{};
+    ca.params = params; ca.t_dev = reinterpret_cast<const long long*>(t_dev); ca.t_host = t_host; ca.scale = scale;
+    ca.out = fb.cond; ca.cond_stride = P.cond_stride;
+    ca.tm0_w = P.tm0_w; ca.tm0_b = P.tm0_b; ca.tm2_w = P.tm2_w; ca.tm2_b = P.tm2_b;
+    for (int l = 0; l < 4; ++l) {
+        ca.mlp_w[l] = P.blk[l].mlp_w; ca.mlp_b[l] = P.blk[l].mlp_b;
+        ca.tr_w[l] = P.blk[l].tr_w; ca.tr_b[l] = P.blk[l].tr_b;
+        ca.cin[l] = P.blk[l].cin; ca.coff[l] = P.blk[l].cond_off;
+    }
+    ca.cond_vec = nullptr; ca.hidden = nullptr;
+    hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(128), 0, st, ca);
+    SINDDM_LAUNCH_CHECK();
+
+    const float* cur = x;
+    int freeb[4] = {0, 1, 2, 3};
+    int curb = -1;
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        // pick three scratch buffers different from the one holding `cur`
+        int sel[3], n = 0;
+        for (int i = 0; i < 4 && n < 3; ++i)
+            if (freeb[i] != curb) sel[n++] = freeb[i];
+        float* hbuf = fb.buf[sel[0]];
+        float* gbuf = fb.buf[sel[1]];
+        float* obuf = fb.buf[sel[2]];
+        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, P.cond_stride, hbuf, B,
+                               b.cin, H, W, st);
+        if (rc) return rc;
+        ConvArgs c1{};
+        c1.in = hbuf; c1.w3 = packed + b.pk_c1; c1.bias = packed + b.pk_b1; c1.out = gbuf;
+        c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch3 = b.nch1; c1.nch1 = 0;
+        c1.coblks = b.coblks; c1.act = 1;
+        rc = conv_launch(c1, b.mt, st);
+        if (rc) return rc;
+        ConvArgs c2{};
+        c2.in = gbuf; c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.out = obuf;
+        c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout; c2.nch3 = b.nch2;
+        if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
+        else { c2.resid = cur; c2.nch1 = 0; }
+        c2.coblks = b.coblks; c2.act = 0;
+        rc = conv_launch(c2, b.mt, st);
+        if (rc) return rc;
+        cur = obuf;
+        curb = sel[2];
+    }
+    const int HW = H * W;
+    hipLaunchKernelGGL(final_conv1x1_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, st, cur, params + P.fin_w,
+                       params + P.fin_b, out, P.half, HW);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sinddm
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+using namespace sinddm;
+
+extern "C" {
+
+int sinddm_abi_version(void) { return SINDDM_ABI_VERSION; }
+
+int64_t sinddm_param_count(int dim) { NetPlan p = make_plan(dim); return p.ok ? p.nparams : -1; }
+int sinddm_param_tensors(int dim) { NetPlan p = make_plan(dim); return p.ok ? p.ntensors : -1; }
+int64_t sinddm_param_offset(int dim, int idx) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || idx < 0 || idx >= p.ntensors) return -1;
+    return p.tensor_off[idx];
+}
+int64_t sinddm_packed_count(int dim) { NetPlan p = make_plan(dim); return p.ok ? p.npacked : -1; }
+
+size_t sinddm_workspace_bytes(int dim, int B, int H, int W) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || B <= 0 || H <= 0 || W <= 0) return 0;
+    return fwd_workspace_bytes(p, B, H, W);
+}
+
+int sinddm_pack_weights(const float* params, float* packed, int dim, void* stream) {
+    if (!params || !packed) return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    return pack_forward(p, params, packed, static_cast<hipStream_t>(stream));
+}
+
+int sinddm_net_forward(const float* params, const float* packed, const float* x, const int64_t* t_dev, int t_host,
+                       float scale, float* out, int dim, int B, int H, int W, void* ws, size_t ws_bytes,
+                       void* stream) {
+    if (!params || !packed || !x || !out || !ws || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    return net_forward_impl(p, params, packed, x, t_dev, t_host, scale, out, B, H, W, ws, ws_bytes,
+                            static_cast<hipStream_t>(stream));
+}
+
+int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, float* out, const float* tab_sqrt_ac,
+                    const float* tab_sqrt_1m_ac, const float* gamma_row, const int64_t* t_dev, int t_host, int B,
+                    int64_t n, void* stream) {
+    if (!x0 || !noise || !out || !tab_sqrt_ac || !tab_sqrt_1m_ac || B <= 0 || n <= 0) return SINDDM_E_BADARG;
+    if (x_orig && !gamma_row) return SINDDM_E_BADARG;
+    long long bx = (n + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+                       x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
+                       reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde, const float* noise, float* out,
+                        const sinddm_step_coefs* coefs, int64_t n, void* stream) {
+    if (!x_t || !eps || !noise || !out || !coefs || n <= 0) return SINDDM_E_BADARG;
+    if (coefs->mode != 0 && !x_tilde) return SINDDM_E_BADARG;
+    long long bx = (n + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(reverse_step_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), x_t,
+                       eps, x_tilde, noise, out, *coefs, (long long)n);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_prof_begin(void) {
+    ConvProfiler& p = conv_profiler();
+    p.on = true;
+    p.used = 0;
+    p.flops = 0.0;
+    return 0;
+}
+
+int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
+    ConvProfiler& p = conv_profiler();
+    p.on = false;
+    double ms = 0.0;
+    for (int i = 0; i < p.used; ++i) {
+        hipError_t e = hipEventSynchronize(p.ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]);
+        if (e != hipSuccess) return (int)e;
+        ms += t;
+    }
+    if (conv_ms_total) *conv_ms_total = ms;
+    if (conv_launches) *conv_launches = p.used;
+    if (conv_flops_total) *conv_flops_total = p.flops;
+    p.used = 0;
+    return 0;
+}
+
+int sinddm_upsample_bilinear(const float* in, float* out, int BC, int h, int w, int H, int W, void* stream) {
+    if (!in || !out || BC <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((H * W + 255) / 256, BC), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in, out, h, w, H, W, sy, sx);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

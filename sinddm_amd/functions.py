@@ -1,0 +1,122 @@
+"""Host-side helpers of the SinDDM hot path (mirror of reference SinDDM/functions.py:72-192).
+
+Everything here is one-off host work (schedule maths in float64 numpy, pyramid construction with
+PIL) or tiny glue; the per-step work lives in the HIP library.
+"""
+from __future__ import annotations
+
+from inspect import isfunction
+from pathlib import Path
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+
+def exists(x) -> bool:                                   # functions.py:72
+    return x is not None
+
+
+def default(val, d):                                     # functions.py:76
+    if exists(val):
+        return val
+    return d() if isfunction(d) else d
+
+
+def cycle(dl):                                           # functions.py:82
+    while True:
+        for data in dl:
+            yield data
+
+
+def num_to_groups(num: int, divisor: int) -> List[int]:  # functions.py:88
+    groups, remainder = divmod(num, divisor)
+    arr = [divisor] * groups
+    if remainder > 0:
+        arr.append(remainder)
+    return arr
+
+
+def loss_backwards(fp16, loss, optimizer, **kwargs):     # functions.py:97 (apex AMP is never enabled)
+    if fp16:
+        raise NotImplementedError("apex mixed precision is not part of the MI355X build (fp16=False in main.py:122)")
+    loss.backward(**kwargs)
+
+
+def extract(a: torch.Tensor, t: torch.Tensor, x_shape) -> torch.Tensor:
+    """a[t] reshaped (B,1,1,1) -- functions.py:105-108.  Kept for API parity; the HIP kernels do
+    this gather themselves (table pointer + t)."""
+    b = t.shape[0]
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def noise_like(shape, device, repeat: bool = False) -> torch.Tensor:   # functions.py:111-114
+    if repeat:
+        return torch.randn((1, *shape[1:]), device=device).repeat(shape[0], *((1,) * (len(shape) - 1)))
+    return torch.randn(shape, device=device)
+
+
+def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> np.ndarray:
+    """Cosine schedule in float64 (functions.py:117-127)."""
+    steps = timesteps + 1
+    grid = np.linspace(0, steps, steps)
+    abar = np.cos(((grid / steps) + s) / (1 + s) * np.pi * 0.5) ** 2
+    abar = abar / abar[0]
+    betas = 1 - (abar[1:] / abar[:-1])
+    return np.clip(betas, a_min=0, a_max=0.999)
+
+
+def pyramid_geometry(image_size: Tuple[int, int], scale_factor: float = 1.411, auto_scale=None):
+    """Integer / float64 bookkeeping of create_img_scales (functions.py:148-174): returns
+    (sizes[(W,H)], scale_factor, n_scales, image_size_used).  No image data involved."""
+    image_size = (int(image_size[0]), int(image_size[1]))
+    if auto_scale is not None:
+        scaler = np.sqrt((image_size[0] * image_size[1]) / auto_scale)
+        if scaler > 1:
+            image_size = (int(image_size[0] / scaler), int(image_size[1] / scaler))
+    area_scale_0 = 3110
+    s_dim, l_dim = min(image_size), max(image_size)
+    scale_0_dim = int(round(np.sqrt(area_scale_0 * s_dim / l_dim)))
+    scale_0_dim = min(max(scale_0_dim, 42), 55)
+    n_scales = int(round((np.log(s_dim / scale_0_dim)) / (np.log(scale_factor))) + 1)
+    scale_factor = np.exp((np.log(s_dim / scale_0_dim)) / (n_scales - 1))
+    sizes = []
+    for i in range(n_scales):
+        f = np.power(scale_factor, n_scales - i - 1)
+        sizes.append((int(round(image_size[0] / f)), int(round(image_size[1] / f))))
+    return sizes, scale_factor, n_scales, image_size
+
+
+def create_img_scales(foldername, filename, scale_factor=1.411, image_size=None, create=False, auto_scale=None):
+    """Build the image pyramid of one training image (functions.py:130-192).
+
+    LANCZOS down-scales into <folder>/scale_i/, BILINEAR re-upsamples of scale i-1 into
+    <folder>/scale_i_recon/, and the wrapped-uint8 Frobenius 'rescale loss' per scale.
+    Returns (sizes[(W,H)], rescale_losses, scale_factor, n_scales) exactly like the reference."""
+    orig_image = Image.open(foldername + filename)
+    filename = filename.rsplit(".", 1)[0] + ".png"
+    if image_size is None:
+        image_size = orig_image.size
+    sizes, scale_factor, n_scales, _ = pyramid_geometry(image_size, scale_factor, auto_scale)
+
+    pyramid = []
+    for i, size in enumerate(sizes):
+        img = orig_image.resize(size, Image.LANCZOS)
+        if create:
+            out_dir = Path(foldername + f"scale_{i}/")
+            out_dir.mkdir(parents=True, exist_ok=True)
+            img.save(str(out_dir / filename))
+        pyramid.append(img)
+
+    rescale_losses = []
+    for i in range(n_scales - 1):
+        recon = pyramid[i].resize(sizes[i + 1], Image.BILINEAR)
+        # uint8 subtraction wraps around, as in the reference (np.subtract on PIL images)
+        diff = np.subtract(pyramid[i + 1], recon)
+        rescale_losses.append(np.linalg.norm(diff) / np.asarray(recon).size)
+        if create:
+            out_dir = Path(foldername + f"scale_{i + 1}_recon/")
+            out_dir.mkdir(parents=True, exist_ok=True)
+            recon.save(str(out_dir / filename))
+    return sizes, rescale_losses, scale_factor, n_scales

@@ -1,0 +1,298 @@
+"""MultiscaleTrainer: training loop, multi-scale sampling driver, checkpoint I/O.
+
+Mirror of reference SinDDM/trainer.py:35-285 (the hot-path part: __init__, train, sample_scales,
+save, load, step_ema, reset_parameters, Dataset).  The interactive application modes
+(image2image, clip_sampling, clip_roi_sampling, roi_guided_sampling -- trainer.py:287-488) are
+outside the MI355X hot-path build.
+"""
+from __future__ import annotations
+
+import copy
+import datetime
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+from torch.optim.lr_scheduler import MultiStepLR
+
+from . import dist as sdist
+from .functions import num_to_groups
+from .models import EMA, SinDDMNet
+from .optim import FusedAdam, ema_update_
+
+
+def image_to_tensor(img: Image.Image) -> torch.Tensor:
+    """PIL RGB uint8 -> float32 CHW in [-1, 1]  (ToTensor + Lambda(t*2-1), trainer.py:46-50)."""
+    a = np.asarray(img.convert('RGB'), dtype=np.uint8)
+    return torch.from_numpy(a.transpose(2, 0, 1).copy()).to(torch.float32).div(255).mul(2).sub(1)
+
+
+def save_image(tensor: torch.Tensor, path: str, nrow: int = 8, padding: int = 2) -> None:
+    """Minimal stand-in for torchvision.utils.save_image (grid of [0,1] images -> PNG). Host side,
+    off the timed path."""
+    t = tensor.detach().float().cpu()
+    if t.dim() == 3:
+        t = t[None]
+    t = t.clamp(0, 1)
+    B, C, H, W = t.shape
+    ncol = min(nrow, B)
+    nrows = (B + ncol - 1) // ncol
+    grid = torch.zeros(C, nrows * (H + padding) + padding, ncol * (W + padding) + padding)
+    for i in range(B):
+        r, c = divmod(i, ncol)
+        y, x = r * (H + padding) + padding, c * (W + padding) + padding
+        grid[:, y:y + H, x:x + W] = t[i]
+    arr = (grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy())
+    Image.fromarray(arr).save(path)
+
+
+class Dataset(torch.utils.data.Dataset):
+    """One training image (and its blurry re-upsampled version) per scale folder (trainer.py:35-63)."""
+
+    def __init__(self, folder, image_size, blurry_img=False, exts=('jpg', 'jpeg', 'png')):
+        super().__init__()
+        self.folder = folder
+        self.image_size = image_size
+        self.blurry_img = blurry_img
+        self.paths = [p for ext in exts for p in Path(f'{folder}').glob(f'**/*.{ext}')]
+        if blurry_img:
+            self.folder_recon = folder + '_recon/'
+            self.paths_recon = [p for ext in exts for p in Path(f'{self.folder_recon}').glob(f'**/*.{ext}')]
+
+    def __len__(self):
+        return len(self.paths) * 128
+
+    def __getitem__(self, index):
+        img = image_to_tensor(Image.open(self.paths[0]))
+        if self.blurry_img:
+            return img, image_to_tensor(Image.open(self.paths_recon[0]))
+        return img
+
+
+class MultiscaleTrainer(object):
+
+    def __init__(self, ms_diffusion_model, folder, *, ema_decay=0.995, n_scales=None, scale_factor=1,
+                 image_sizes=None, train_batch_size=32, train_lr=2e-5, train_num_steps=100000,
+                 gradient_accumulate_every=2, fp16=False, step_start_ema=2000, update_ema_every=10,
+                 save_and_sample_every=25000, avg_window=100, sched_milestones=None, results_folder='./results',
+                 device=None):
+        super().__init__()
+        self.device = device
+        self.sched_milestones = [10000, 30000, 60000, 80000, 90000] if sched_milestones is None else sched_milestones
+        if image_sizes is None:
+            image_sizes = []
+        self.model = ms_diffusion_model
+        self.ema = EMA(ema_decay)
+        self.ema_decay = ema_decay
+        self.ema_model = copy.deepcopy(self.model)
+        self.update_ema_every = update_ema_every
+        self.step_start_ema = step_start_ema
+        self.save_and_sample_every = save_and_sample_every
+        self.avg_window = avg_window
+        self.batch_size = train_batch_size
+        self.n_scales = n_scales
+        self.scale_factor = scale_factor
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_num_steps = train_num_steps
+
+        self.input_paths = []
+        self.ds_list = []
+        self.data_list = []
+        self.results_folder = Path(results_folder)
+        self.results_folder.mkdir(parents=True, exist_ok=True)
+
+        # one batch of B identical copies per scale, parked on the device (trainer.py:113-132)
+        for i in range(n_scales):
+            self.input_paths.append(folder + 'scale_' + str(i))
+            ds = Dataset(self.input_paths[i], image_sizes[i], blurry_img=i > 0)
+            self.ds_list.append(ds)
+            item = ds[0]
+            rep = lambda t: t[None].repeat(train_batch_size, 1, 1, 1).contiguous().to(self.device)
+            if i > 0:
+                self.data_list.append((rep(item[0]), rep(item[1])))
+            else:
+                self.data_list.append((rep(item), rep(item)))
+
+        if fp16:
+            raise NotImplementedError('apex mixed precision is never enabled by main.py (fp16=False, main.py:122)')
+        self.fp16 = fp16
+
+        if isinstance(self.model.denoise_fn, SinDDMNet):
+            self.opt = FusedAdam(self.model.denoise_fn, lr=train_lr)
+        else:
+            self.opt = torch.optim.Adam(ms_diffusion_model.parameters(), lr=train_lr)
+        self.scheduler = MultiStepLR(self.opt, milestones=self.sched_milestones, gamma=0.5)
+
+        self.step = 0
+        self.running_loss = []
+        self.running_scale = []
+        self.avg_t = []
+        # optional injection hooks for parity tests: scale_fn(step) -> int
+        self.scale_fn = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.ema_model.load_state_dict(self.model.state_dict())
+
+    def step_ema(self):
+        """Copy until step_start_ema, then ema = decay*ema + (1-decay)*p  (trainer.py:155-159)."""
+        if self.step < self.step_start_ema:
+            self.reset_parameters()
+            return
+        src, dst = self.model.denoise_fn, self.ema_model.denoise_fn
+        if isinstance(src, SinDDMNet) and isinstance(dst, SinDDMNet):
+            ema_update_(dst, src, self.ema_decay)
+        else:
+            self.ema.update_model_average(self.ema_model, self.model)
+
+    def save(self, milestone):
+        data = {
+            'step': self.step,
+            'model': self.model.state_dict(),
+            'ema': self.ema_model.state_dict(),
+            'sched': self.scheduler.state_dict(),
+            'running_loss': self.running_loss,
+            'running_scale': self.running_scale,
+        }
+        if isinstance(self.opt, FusedAdam):
+            data['opt'] = self.opt.state_dict()       # extra key (the reference omits Adam state)
+        torch.save(data, str(self.results_folder / f'model-{milestone}.pt'))
+        try:
+            import matplotlib
+            matplotlib.use('Agg')
+            from matplotlib import pyplot as plt
+            plt.rcParams['figure.figsize'] = [16, 8]
+            plt.plot(self.running_loss)
+            plt.grid(True)
+            plt.ylim((0, 0.2))
+            plt.savefig(str(self.results_folder / 'running_loss'))
+            plt.clf()
+        except Exception:
+            pass
+
+    def load(self, milestone):
+        data = torch.load(str(self.results_folder / f'model-{milestone}.pt'), map_location=self.device,
+                          weights_only=False)
+        self.step = data['step']
+        self.model.load_state_dict(data['model'])
+        self.ema_model.load_state_dict(data['ema'])
+        self.scheduler.load_state_dict(data['sched'])
+        self.running_loss = data['running_loss']
+        if 'opt' in data and isinstance(self.opt, FusedAdam):
+            self.opt.load_state_dict(data['opt'])
+
+    def _pick_scale(self, weights: torch.Tensor) -> int:
+        if self.scale_fn is not None:
+            return int(self.scale_fn(self.step))
+        return int(torch.multinomial(input=weights, num_samples=1))     # trainer.py:197 (host draw: no sync)
+
+    def train(self):
+        loss_acc = None
+        s_weights = torch.tensor(self.model.num_timesteps_trained, dtype=torch.float)
+        while self.step < self.train_num_steps:
+            s = self._pick_scale(s_weights)
+            for _ in range(self.gradient_accumulate_every):
+                data = self.data_list[s]
+                loss = self.model(data, s)
+                d = loss.detach()
+                loss_acc = d if loss_acc is None else loss_acc + d
+                (loss / self.gradient_accumulate_every).backward()
+            if self.step % self.avg_window == 0:
+                avg = float(loss_acc) / self.avg_window          # the only device->host sync of the loop
+                print(f'step:{self.step} loss:{avg}')
+                self.running_loss.append(avg)
+                loss_acc = None
+            self.opt.step()
+            self.opt.zero_grad()
+            if self.step % self.update_ema_every == 0:
+                self.step_ema()
+            self.scheduler.step()
+            self.step += 1
+            if self.step % self.save_and_sample_every == 0:
+                milestone = self.step // self.save_and_sample_every
+                batches = num_to_groups(16, self.batch_size)
+                all_images = torch.cat([self.ema_model.sample(batch_size=n) for n in batches], dim=0)
+                all_images = (all_images + 1) * 0.5
+                save_image(all_images, str(self.results_folder / f'sample-{milestone}.png'), nrow=4)
+                self.save(milestone)
+        print('training completed')
+
+    @torch.no_grad()
+    def sample_scales(self, scale_mul=None, batch_size=16, custom_sample=False, custom_image_size_idxs=None,
+                      custom_scales=None, image_name='', start_noise=True, custom_t_list=None, desc=None,
+                      save_unbatched=True, save_images=True) -> List[torch.Tensor]:
+        """Drive the sampler over all scales (trainer.py:226-285).  Under torch.distributed the batch is
+        sharded over ranks as independent chains and gathered with one all-gather per scale
+        (RCCL over xGMI on MI355X); returns the list of per-scale (global) sample batches."""
+        if desc is None:
+            desc = f'sample_{str(datetime.datetime.now()).replace(":", "_")}'
+        if self.ema_model.reblurring:
+            desc = desc + '_rblr'
+        if self.ema_model.sample_limited_t:
+            desc = desc + '_t_lmtd'
+        if custom_t_list is None:
+            custom_t_list = self.ema_model.num_timesteps_ideal[1:]
+        if custom_scales is None:
+            custom_scales = [*range(self.n_scales)]
+            n_scales = self.n_scales
+        else:
+            n_scales = len(custom_scales)
+        if custom_image_size_idxs is None:
+            custom_image_size_idxs = [*range(self.n_scales)]
+        final_results_folder = Path(str(self.results_folder / 'final_samples'))
+        if scale_mul is not None:
+            scale_0_size = (int(self.model.image_sizes[custom_image_size_idxs[0]][0] * scale_mul[0]),
+                            int(self.model.image_sizes[custom_image_size_idxs[0]][1] * scale_mul[1]))
+        else:
+            scale_0_size = None
+            scale_mul = (1, 1)
+        t_list = [self.ema_model.num_timesteps_trained[0]] + list(custom_t_list)
+        res_sub_folder = '_'.join(str(e) for e in t_list)
+
+        local_b = sdist.local_batch(batch_size)          # this rank's independent chains
+        is_main = sdist.rank() == 0
+        if save_images and is_main:
+            final_results_folder.mkdir(parents=True, exist_ok=True)
+
+        local_samples: List[torch.Tensor] = []
+        gathered: List[torch.Tensor] = []
+        final_img = None
+        for i in range(n_scales):
+            if start_noise and i == 0:
+                cur = self.ema_model.sample(batch_size=local_b, scale_0_size=scale_0_size, s=custom_scales[i])
+            elif i == 0:
+                orig = Image.open((self.input_paths[custom_scales[i]] + '/' + image_name)).convert('RGB')
+                cur = image_to_tensor(orig).repeat(local_b, 1, 1, 1).to(self.device)
+            else:
+                cur = self.ema_model.sample_via_scale(local_b, local_samples[i - 1], s=custom_scales[i],
+                                                      scale_mul=scale_mul, custom_sample=custom_sample,
+                                                      custom_img_size_idx=custom_image_size_idxs[i],
+                                                      custom_t=custom_t_list[int(custom_scales[i]) - 1])
+            local_samples.append(cur)
+            full = sdist.gather_batch(cur, batch_size)   # no-op on a single process
+            gathered.append(full)
+            if save_images and is_main:
+                final_img = (full + 1) * 0.5
+                save_image(final_img, str(final_results_folder / res_sub_folder)
+                           + f'_out_s{i}_{desc}_sm_{scale_mul[0]}_{scale_mul[1]}.png', nrow=4)
+        if save_images and save_unbatched and is_main and final_img is not None:
+            unb = Path(str(self.results_folder / f'final_samples_unbatched_{desc}'))
+            unb.mkdir(parents=True, exist_ok=True)
+            for b in range(final_img.shape[0]):
+                save_image(final_img[b], str(unb / res_sub_folder) + f'_out_b{b}.png')
+        return gathered
+
+    # ---- application modes of the reference (out of the hot-path scope) ----
+    def image2image(self, *a, **k):
+        raise NotImplementedError('harmonization / style transfer drivers are outside the MI355X hot-path build')
+
+    def clip_sampling(self, *a, **k):
+        raise NotImplementedError('CLIP guided sampling is outside the MI355X hot-path build')
+
+    def clip_roi_sampling(self, *a, **k):
+        raise NotImplementedError('CLIP ROI sampling is outside the MI355X hot-path build')
+
+    def roi_guided_sampling(self, *a, **k):
+        raise NotImplementedError('ROI guided sampling is outside the MI355X hot-path build')

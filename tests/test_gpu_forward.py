@@ -1,0 +1,183 @@
+"""GPU parity tests of the forward / sampling path: HIP library (through the C ABI) vs the CPU oracle and
+vs the golden fixtures produced by the reference.  Tolerances are fp32 reduction-order tolerances."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import max_abs, rel_l2
+from oracle import sinddm_oracle as O
+from sinddm_amd.synth import closed_form_state_dict, closed_form_tensor, hash_randn, noise_key
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net(dim):
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    return net
+
+
+def _diffusion(golden, dim, cfg="C1", **kw):
+    from sinddm_amd.models import MultiScaleGaussianDiffusion
+    meta = golden("g11_img_scales.json")[cfg]
+    net = _net(dim)
+    d = MultiScaleGaussianDiffusion(net, n_scales=meta["n_scales"], scale_factor=meta["scale_factor"],
+                                    image_sizes=[tuple(s) for s in meta["sizes"]], timesteps=meta["T"],
+                                    train_full_t=True, scale_losses=meta["rescale_losses"], loss_factor=1,
+                                    loss_type="l1", device=DEV, reblurring=True, omega=0, **kw).to(DEV)
+    sched = O.make_schedule(meta["T"], meta["n_scales"], meta["rescale_losses"], 1, train_full_t=True)
+    return net, d, sched, meta
+
+
+def test_library_loaded_and_layout():
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    assert lib.sinddm_abi_version() == 1
+    assert lib.sinddm_param_count(160) == 1106772
+
+
+@pytest.mark.parametrize("dim,H,W", [(160, 37, 41), (32, 67, 90), (160, 24, 50)])
+def test_net_forward_golden(golden, dim, H, W):
+    """G3: SinDDMNet.forward vs the reference's own outputs (distinct t per sample, s=0 and s=2)."""
+    g = golden("g3_net.npz")
+    net = _net(dim)
+    x = closed_form_tensor((2, 3, H, W), phase=0.3, amp=1.2).to(DEV)
+    t = torch.tensor([17, 3], device=DEV)
+    for s in (0, 2):
+        with torch.no_grad():
+            y = net(x, t, scale=s)
+        assert rel_l2(y.cpu(), g[f"d{dim}_{H}x{W}_s{s}"]) < 1e-5
+
+
+@pytest.mark.parametrize("dim,B,H,W", [(160, 1, 5, 7), (160, 3, 8, 32), (160, 2, 9, 33), (160, 1, 48, 64),
+                                       (32, 2, 17, 100), (16, 1, 33, 31), (160, 2, 94, 126)])
+def test_net_forward_vs_oracle_edges(dim, B, H, W):
+    """Ragged / tiny / tile-boundary sizes against the oracle; host-t and device-t paths agree."""
+    net = _net(dim)
+    sd = closed_form_state_dict(dim)
+    x = hash_randn((B, 3, H, W), 11 + H)
+    t = torch.arange(B) * 7 + 2
+    ref = O.net_forward(sd, x, t, 1)
+    with torch.no_grad():
+        y = net(x.to(DEV), t.to(DEV), scale=1)
+    assert rel_l2(y.cpu(), ref) < 1e-5
+    t0 = int(t[0])
+    y2 = net.infer(x[:1].to(DEV).contiguous(), None, t0, 1.0)
+    assert rel_l2(y2.cpu(), ref[:1]) < 1e-5
+
+
+def test_q_sample_golden(golden):
+    net, d, sched, _ = _diffusion(golden, 32)
+    x0 = closed_form_tensor((3, 3, 20, 30), phase=0.2).to(DEV)
+    nz = hash_randn((3, 3, 20, 30), 77).to(DEV)
+    y = d.q_sample(x0, torch.tensor([0, 41, 99], device=DEV), noise=nz)
+    assert max_abs(y.cpu(), golden("g7_qsample.npz")["y"]) <= 1e-6
+
+
+def test_q_sample_mix_vs_oracle(golden):
+    net, d, sched, _ = _diffusion(golden, 32)
+    xs = hash_randn((4, 3, 13, 21), 1)
+    xo = hash_randn((4, 3, 13, 21), 2)
+    nz = hash_randn((4, 3, 13, 21), 3)
+    t = torch.tensor([0, 5, 50, 99])
+    ref = O.p_losses_inputs(sched, xs, t, 2, nz, xo)
+    gamma_row = d.gammas[1].reshape(-1).contiguous()
+    y = d._q_sample_impl(xs.to(DEV), t.to(DEV), 0, nz.to(DEV), x_orig=xo.to(DEV), gamma_row=gamma_row)
+    assert max_abs(y.cpu(), ref) <= 2e-6
+
+
+def test_upsample_golden(golden):
+    net, d, _, _ = _diffusion(golden, 32)
+    g = golden("g8_bilinear.npz")
+    for (h, w), (H, W), Cc in (((48, 64), (67, 90), 3), ((133, 177), (186, 248), 1), ((46, 69), (92, 276), 2),
+                               ((67, 90), (94, 126), 3)):
+        x = closed_form_tensor((1, Cc, h, w), phase=0.9, amp=1.0, freq=0.271).to(DEV)
+        y = d.upsample(x, (H, W))
+        assert max_abs(y.cpu(), g[f"{h}x{w}_to_{H}x{W}"]) < 2e-5
+
+
+def test_reverse_step_all_modes_vs_oracle(golden):
+    """The fused reverse-step kernel against the oracle for every branch (s=0 / s>0, t>0 / t=0,
+    clip on/off, omega 0 / >0, reblurring off)."""
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    net, d, sched, _ = _diffusion(golden, 32)
+    shape = (2, 3, 19, 23)
+    x = (hash_randn(shape, 5) * 1.3)
+    eps = hash_randn(shape, 6)
+    xt = hash_randn(shape, 7) * 0.7
+    z = hash_randn(shape, 8)
+    xd, ed, td_, zd = x.to(DEV), eps.to(DEV), xt.to(DEV), z.to(DEV)   # keep the device copies alive
+    for reblur in (True, False):
+        for omega in (0.0, 0.3):
+            d.reblurring, d.omega = reblur, omega
+            for s in (0, 1, 2):
+                for t in (99, 17, 1, 0):
+                    for clip in (True, False):
+                        ref = O.reverse_step(sched, x, eps, t, s, z, xt, reblurring=reblur, omega=omega,
+                                             clip_denoised=clip)
+                        k = d.step_coefs(t, s, clip)
+                        out = torch.empty(shape, device=DEV)
+                        rc = lib.sinddm_reverse_step(xd.data_ptr(), ed.data_ptr(), td_.data_ptr(), zd.data_ptr(),
+                                                     out.data_ptr(), C.byref(k), out.numel(),
+                                                     torch.cuda.current_stream().cuda_stream)
+                        assert rc == 0
+                        torch.cuda.synchronize()
+                        err = max_abs(out.cpu(), ref)
+                        assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (reblur, omega, s, t, clip, err)
+    d.reblurring, d.omega = True, 0
+
+
+def test_p_sample_golden(golden):
+    """G6: whole p_sample (net + fused step) vs the reference with recorded noise."""
+    g = golden("g6_psample.npz")
+    net, d, sched, _ = _diffusion(golden, 32)
+    for s, (H, W) in ((0, (48, 64)), (2, (94, 126))):
+        for t in (17, 1, 0):
+            x = closed_form_tensor((2, 3, H, W), phase=0.5 + t, amp=1.1).to(DEV)
+            d.img_prev_upsample = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211).to(DEV)
+            d.noise_fn = lambda kind, shape, ss, tt, dev: hash_randn(shape, noise_key(kind, ss, tt)).to(dev)
+            y = d.p_sample(x, torch.full((2,), t, device=DEV, dtype=torch.long), s)
+            assert rel_l2(y.cpu(), g[f"psample_s{s}_t{t}"]) < 1e-5, (s, t)
+            with torch.no_grad():
+                e = net(x, torch.full((2,), t, device=DEV, dtype=torch.long), scale=s)
+            assert rel_l2(e.cpu(), g[f"eps_s{s}_t{t}"]) < 1e-5, (s, t)
+
+
+def test_full_chain_c1_golden(golden):
+    """G9: full 3-scale C1 chain (T=100, B=1, dim=160, 193 net evaluations) through the public
+    sample()/sample_via_scale() API with hash noise: within the north_star's 1e-4 rel-L2 of the
+    reference's images."""
+    g = golden("g9_chain_c1.npz")
+    net, d, sched, meta = _diffusion(golden, 160)
+    assert d.num_timesteps_ideal == list(g["ideal"])
+    d.noise_fn = lambda kind, shape, s, t, dev: hash_randn(shape, noise_key(kind, s, t)).to(dev)
+    outs = [d.sample(batch_size=1, s=0)]
+    for s in range(1, meta["n_scales"]):
+        outs.append(d.sample_via_scale(1, outs[-1], s=s, scale_mul=(1, 1), custom_sample=True,
+                                       custom_img_size_idx=s, custom_t=d.num_timesteps_ideal[1:][s - 1]))
+    for i, o in enumerate(outs):
+        assert tuple(o.shape[2:]) == tuple(meta["image_sizes_hw"][i])
+        assert rel_l2(o.cpu(), g[f"out_s{i}"]) < 1e-4, i
+
+
+def test_sampler_properties_full_size(golden):
+    """Size-independent properties at the C2 finest size (186x248, B=4): batch independence (each
+    sample's result does not depend on its neighbours) and determinism."""
+    net, d, sched, meta = _diffusion(golden, 160, cfg="C2")
+    H, W = meta["image_sizes_hw"][-1]
+    s = meta["n_scales"] - 1
+    x = hash_randn((4, 3, H, W), 21).to(DEV)
+    d.img_prev_upsample = hash_randn((4, 3, H, W), 22).to(DEV) * 0.5
+    d.noise_fn = lambda kind, shape, ss, tt, dev: hash_randn((4, 3, H, W), 23)[: shape[0]].to(dev)
+    y4 = d._p_sample_host_t(x, 100, s)
+    y4b = d._p_sample_host_t(x, 100, s)
+    assert torch.equal(y4, y4b)
+    d.img_prev_upsample = d.img_prev_upsample[:1].contiguous()
+    y1 = d._p_sample_host_t(x[:1].contiguous(), 100, s)
+    assert torch.equal(y1, y4[:1])
+    assert torch.isfinite(y4).all()
