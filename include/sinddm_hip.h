@@ -97,6 +97,43 @@ int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde
 int sinddm_upsample_bilinear(const float* in, float* out, int BC, int h, int w, int H, int W,
                              void* stream);
 
+/* ---- training ------------------------------------------------------------------------------ */
+/* Scratch for one training forward+backward of a (B,3,H,W) batch: saved activations (about
+ * 1843 floats per pixel per sample at dim=160) + backward scratch. */
+size_t sinddm_train_workspace_bytes(int dim, int B, int H, int W);
+
+/* Transposed / tap-flipped weight images for the data-gradient convolutions (rebuild after every
+ * parameter update, like sinddm_pack_weights). */
+int64_t sinddm_packed_bwd_count(int dim);
+int sinddm_pack_weights_bwd(const float* params, float* packed_bwd, int dim, void* stream);
+
+/* Same as sinddm_net_forward, but keeps every activation the backward needs inside `ws`
+ * (layout private to the library).  `ws` must stay untouched until sinddm_net_backward ran.
+ * Replaces the autograd-recording forward of reference SinDDM/models.py:587,591. */
+int sinddm_net_forward_train(const float* params, const float* packed, const float* x,
+                             const int64_t* t_dev, int t_host, float scale, float* out,
+                             int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of SinDDMNet: given grad_out = dL/d eps (B,3,H,W), ACCUMULATES (+=) dL/d params into
+ * grad_params (same flat layout as params) and, if grad_x != NULL, writes dL/dx.
+ * Replaces loss.backward() through the net (reference SinDDM/functions.py:97-102, trainer.py:202). */
+int sinddm_net_backward(const float* params, const float* packed, const float* packed_bwd,
+                        const float* x, const float* grad_out, float* grad_params, float* grad_x,
+                        int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
+
+/* loss_out[0] += mean(|noise - eps|)  (caller zeroes loss_out);  if grad_out != NULL:
+ * grad_out = -sign(noise - eps)/n * grad_scale.           reference SinDDM/models.py:594 */
+int sinddm_l1_loss_fwd_bwd(const float* noise, const float* eps, float* loss_out, float* grad_out,
+                           int64_t n, float grad_scale, void* stream);
+
+/* Fused optimizer / EMA over flat buffers of n floats.  mode bits: 1 = Adam update of p from g
+ * (torch.optim.Adam defaults, reference trainer.py:134,208; step_size = lr/(1-beta1^k),
+ * bc2_sqrt = sqrt(1-beta2^k)); 2 = ema := p (copy phase, trainer.py:156-158);
+ * 4 = ema := ema_decay*ema + (1-ema_decay)*p (models.py:28-31). */
+int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, float step_size,
+                         float beta1, float beta2, float eps, float bc2_sqrt, float ema_decay,
+                         float reserved, int mode, int64_t n, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg) ----------------------------------------------
  * Between prof_begin and prof_end every MFMA conv launch is bracketed by hipEvents on the stream it
  * is launched on; prof_end synchronises those events and returns the summed kernel time (ms), the

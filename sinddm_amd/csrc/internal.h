@@ -1,0 +1,46 @@
+// Declarations shared between the forward and backward translation units of libsinddm_hip.so.
+#pragma once
+#include "common.h"
+
+namespace sinddm {
+
+struct PackSeg {
+    long long dst;     // offset in packed
+    long long count;   // elements in this segment
+    long long w;       // source weight offset (conv: [cout][cin][taps]), or bias offset
+    long long w2;      // second bias offset to add (-1 none)
+    int kind;          // 0: conv chunks, 1: bias
+    int cin, cout, taps, nch, mt, co_lds;
+    int transpose;     // 1: data-gradient image (M = cin of the forward conv, taps flipped)
+};
+struct PackArgs {
+    PackSeg seg[24];
+    int nseg;
+    long long total;
+};
+int pack_launch(const float* params, float* packed, const PackArgs& a, hipStream_t st);
+
+// Saved activations (training forward) + backward scratch, carved from the caller's workspace.
+struct TrainBufs {
+    float* cond;    // [B][cond_stride]   per-sample conv-block biases
+    float* emb;     // [B][64]            sinusoidal embedding
+    float* hpre;    // [B][128]           time_mlp hidden, pre-GELU
+    float* cvec;    // [B][32]            cond vector, pre-GELU
+    float* mvec;    // [B][4][32]         per-block mlp outputs
+    float* h[4];    // dw5x5 + cond output          (cin  channels)
+    float* u[4];    // conv1 pre-activation         (cout channels)
+    float* g[4];    // GELU(u)                      (cout channels)
+    float* o[4];    // block output                 (cout channels)
+    float* s[4];    // backward scratch, dim channels each
+    float* dcond;   // [B][cond_stride]
+    float* small;   // cond-path backward scratch  [B][4*32 + 32 + 128]
+};
+
+int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
+                     int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
+                     hipStream_t st, const TrainBufs* tb);
+
+int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
+                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st);
+
+}  // namespace sinddm

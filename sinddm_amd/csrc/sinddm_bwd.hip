@@ -1,0 +1,664 @@
+// Training path of the SinDDM hot path for gfx950: activation-saving forward, backward
+// (data gradients through the same MFMA conv kernel with transposed weights, weight gradients on a
+// dedicated MFMA kernel with pixels as the GEMM K dimension), L1 loss, fused Adam / EMA.
+// Replaces autograd through SinDDMNet + torch.optim.Adam + EMA of the reference
+// (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
+#include "conv_mfma.h"
+#include "internal.h"
+
+namespace sinddm {
+
+// =====================================================================================
+// weight-gradient MFMA kernel
+//   gw[co][ci][tap] += sum_{b,y,x} dout[b][co][y][x] * in[b][ci][y+dy-1][x+dx-1]
+// GEMM view: M = co (16-row tiles), N = ci (one 16-col tile per tap), K = pixels (4 per MFMA).
+// A workgroup owns one (co-block of MT*16, ci-block of 16) slab of the gradient and walks a strided
+// subset of the 4x32 pixel tiles; its 4 waves split the tile's rows (K split), each holding all
+// MT x TAPS accumulator tiles in registers across the whole walk.  At the end the 4 partial slabs are
+// combined in LDS and added to the global gradient with one atomic per element.
+// LDS strides == 2 (mod 32) make both operand reads (lane -> channel*stride + pixel) conflict-free.
+// =====================================================================================
+constexpr int WG_THREADS = 256;
+constexpr int WG_TH = 4, WG_TW = 32;
+constexpr int WG_CI = 16;
+constexpr int WG_PSO = WG_TH * WG_TW + 2;              // 130
+constexpr int WG_IRS = WG_TW + 2;                      // 34
+constexpr int WG_IHR = WG_TH + 2;                      // 6
+constexpr int WG_PSI = ((WG_IHR * WG_IRS - 2 + 31) / 32) * 32 + 2;   // 226
+
+struct WgradArgs {
+    const float* dout;   // [B][Cout][H][W]
+    const float* in;     // [B][Cin][H][W]
+    float* gw;           // [Cout][Cin][TAPS]   (+=)
+    float* gb;           // [Cout] (+=) or nullptr
+    int B, H, W, Cin, Cout;
+    int coblks, ciblks, S;
+    int tilesX, tilesY, ntiles;
+};
+
+template <int MT, int TAPS>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sO = smem;                       // [MT*16][WG_PSO]
+    float* sI = smem + MT * 16 * WG_PSO;    // [16][WG_PSI]
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int pairs = p.coblks * p.ciblks;
+    const int q = slot % pairs;
+    const int s = (slot / pairs) * 8 + xcd;          // pixel-split index; same-split slabs share an XCD/L2
+    const int cb = q / p.ciblks, cib = q - cb * p.ciblks;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int tpi = p.tilesX * p.tilesY;
+
+    f32x4 acc[MT][TAPS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bsum[mt] = 0.f;
+
+    for (int tile = s; tile < p.ntiles; tile += p.S) {
+        const int b = tile / tpi;
+        const int tr = tile - b * tpi;
+        const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+        const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+        __syncthreads();
+        // dout tile: MT*16 channels x (4 x 32) pixels, zero outside the image / channel range
+        for (int idx = tid; idx < MT * 16 * WG_TH * WG_TW; idx += WG_THREADS) {
+            const int col = idx / (WG_TH * WG_TW);
+            const int e = idx - col * (WG_TH * WG_TW);
+            const int r = e / WG_TW, c = e - r * WG_TW;
+            const int co = cb * MT * 16 + col;
+            const int gy = y0 + r, gx = x0 + c;
+            float v = 0.f;
+            if (co < p.Cout && gy < H && gx < W) v = p.dout[((size_t)b * p.Cout + co) * HW + (size_t)gy * W + gx];
+            sO[col * WG_PSO + e] = v;
+        }
+        // input tile with 1-pixel halo: 16 channels x (6 x 34)
+        for (int idx = tid; idx < WG_CI * WG_IHR * WG_IRS; idx += WG_THREADS) {
+            const int cil = idx / (WG_IHR * WG_IRS);
+            const int e = idx - cil * (WG_IHR * WG_IRS);
+            const int r = e / WG_IRS, c = e - r * WG_IRS;
+            const int ci = cib * WG_CI + cil;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            float v = 0.f;
+            if (ci < p.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = p.in[((size_t)b * p.Cin + ci) * HW + (size_t)gy * W + gx];
+            sI[cil * WG_PSI + e] = v;
+        }
+        __syncthreads();
+        // wave `wave` owns tile row `wave`: 8 k-steps of 4 consecutive pixels
+        const int aBase = l16 * WG_PSO + wave * WG_TW + kq;
+        const int bBase = l16 * WG_PSI + wave * WG_IRS + kq;
+#pragma unroll 1
+        for (int j = 0; j < WG_TW / 4; ++j) {
+            float a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                a[mt] = sO[aBase + mt * 16 * WG_PSO + 4 * j];
+                bsum[mt] += a[mt];
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = (TAPS == 9) ? t / 3 : 1;
+                const int dx = (TAPS == 9) ? t % 3 : 1;
+                const float bv = sI[bBase + dy * WG_IRS + 4 * j + dx];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- combine the 4 waves' partial slabs in LDS, then one global atomic per element ----
+    __syncthreads();
+    constexpr int SLAB = MT * 16 * WG_CI * TAPS;
+    float* sR = smem;            // SLAB floats (fits: SLAB <= MT*16*WG_PSO + 16*WG_PSI for TAPS <= 9)
+    float* sB = smem + SLAB;     // MT*16 floats
+    for (int i = tid; i < SLAB + MT * 16; i += WG_THREADS) sR[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // C layout: col = lane&15 -> ci (N), row = (lane>>4)*4 + r -> co (M)
+                const int col = mt * 16 + kq * 4 + r;
+                atomicAdd(&sR[(col * WG_CI + l16) * TAPS + t], acc[mt][t][r]);
+            }
+        }
+        float v = bsum[mt];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kq == 0) atomicAdd(&sB[mt * 16 + l16], v);
+    }
+    __syncthreads();
+    for (int i = tid; i < SLAB; i += WG_THREADS) {
+        const int col = i / (WG_CI * TAPS);
+        const int rem = i - col * (WG_CI * TAPS);
+        const int cil = rem / TAPS, t = rem - cil * TAPS;
+        const int co = cb * MT * 16 + col, ci = cib * WG_CI + cil;
+        if (co < p.Cout && ci < p.Cin) atomicAdd(&p.gw[((size_t)co * p.Cin + ci) * TAPS + t], sR[i]);
+    }
+    if (p.gb && cib == 0) {
+        for (int i = tid; i < MT * 16; i += WG_THREADS) {
+            const int co = cb * MT * 16 + i;
+            if (co < p.Cout) atomicAdd(&p.gb[co], sB[i]);
+        }
+    }
+}
+
+template <int MT, int TAPS>
+static void wgrad_launch_t(const WgradArgs& a, unsigned grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)(MT * 16 * WG_PSO + WG_CI * WG_PSI) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_mfma_kernel<MT, TAPS>), dim3(grid), dim3(WG_THREADS), lds, st, a);
+}
+
+static int wgrad_launch(const float* dout, const float* in, float* gw, float* gb, int B, int H, int W, int Cin,
+                        int Cout, int taps, hipStream_t st) {
+    WgradArgs a{};
+    a.dout = dout; a.in = in; a.gw = gw; a.gb = gb;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    const int mt = mt_for(Cout);
+    a.coblks = (Cout + mt * 16 - 1) / (mt * 16);
+    a.ciblks = (Cin + WG_CI - 1) / WG_CI;
+    a.tilesX = (W + WG_TW - 1) / WG_TW;
+    a.tilesY = (H + WG_TH - 1) / WG_TH;
+    a.ntiles = B * a.tilesX * a.tilesY;
+    const int pairs = a.coblks * a.ciblks;
+    int S = (1024 / pairs) / 8 * 8;
+    if (S < 8) S = 8;
+    const int cap = (a.ntiles + 7) / 8 * 8;
+    if (S > cap) S = cap;
+    a.S = S;
+    const unsigned grid = (unsigned)(pairs * S);
+    if (taps == 9) {
+        if (mt == 5) wgrad_launch_t<5, 9>(a, grid, st);
+        else if (mt == 2) wgrad_launch_t<2, 9>(a, grid, st);
+        else wgrad_launch_t<1, 9>(a, grid, st);
+    } else {
+        if (mt == 5) wgrad_launch_t<5, 1>(a, grid, st);
+        else if (mt == 2) wgrad_launch_t<2, 1>(a, grid, st);
+        else wgrad_launch_t<1, 1>(a, grid, st);
+    }
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+// =====================================================================================
+// depthwise 5x5 weight / bias / condition gradients (HBM-bound: reads dh and x once)
+//   gw[c][tap] += sum_{b,p} dh[b][c][p] * x[b][c][p+tap-2];  gb[c] += sum dh;  dcond[b][c] = sum_p dh
+// =====================================================================================
+constexpr int DWB_TH = 16, DWB_TW = 64, DWB_RS = DWB_TW + 4, DWB_HR = DWB_TH + 4;
+
+__global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                            float* __restrict__ gw, float* __restrict__ gb,
+                                                            float* __restrict__ dcond, int cond_stride, int C, int H,
+                                                            int W) {
+    __shared__ __attribute__((aligned(16))) float tile[DWB_HR * DWB_RS];
+    __shared__ float red[4][26];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xs = x + plane;
+    const float* ds = dh + plane;
+    const int tilesX = (W + DWB_TW - 1) / DWB_TW, tilesY = (H + DWB_TH - 1) / DWB_TH;
+    const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    float acc[26];
+#pragma unroll
+    for (int k = 0; k < 26; ++k) acc[k] = 0.f;
+    for (int t = 0; t < tilesX * tilesY; ++t) {
+        const int ty = t / tilesX, tx = t - ty * tilesX;
+        const int y0 = ty * DWB_TH, x0 = tx * DWB_TW;
+        __syncthreads();
+        for (int i = threadIdx.x; i < DWB_HR * DWB_RS; i += 256) {
+            const int rr = i / DWB_RS, cc = i - rr * DWB_RS;
+            const int gy = y0 + rr - 2, gx = x0 + cc - 2;
+            tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xs[(size_t)gy * W + gx] : 0.0f;
+        }
+        __syncthreads();
+        const int gy = y0 + r, gx = x0 + xg * 4;
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = (gy < H && gx + i < W) ? ds[(size_t)gy * W + gx + i] : 0.f;
+        acc[25] += (d[0] + d[1]) + (d[2] + d[3]);
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+            const float4 lo = *reinterpret_cast<const float4*>(&tile[(r + dy) * DWB_RS + xg * 4]);
+            const float4 hi = *reinterpret_cast<const float4*>(&tile[(r + dy) * DWB_RS + xg * 4 + 4]);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) {
+                float sacc = acc[dy * 5 + dx];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sacc = fmaf(d[i], v[dx + i], sacc);
+                acc[dy * 5 + dx] = sacc;
+            }
+        }
+    }
+    // block reduction of the 26 partial sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 26; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 26) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < 25) atomicAdd(&gw[c * 25 + threadIdx.x], v);
+        else {
+            atomicAdd(&gb[c], v);
+            dcond[(size_t)b * cond_stride + c] = v;
+        }
+    }
+}
+
+// =====================================================================================
+// conditioning-path backward (tiny; ONE workgroup, phases separated by __syncthreads)
+// =====================================================================================
+struct CondBwdArgs {
+    const float* params;
+    float* grads;
+    const float* dcond;   // [B][cs]
+    const float* emb;     // [B][64]
+    const float* hpre;    // [B][128]
+    const float* cvec;    // [B][32]
+    const float* mvec;    // [B][4][32]
+    float* dm;            // [B][4][32]  scratch
+    float* dcv;           // [B][32]     scratch
+    float* dh1;           // [B][128]    scratch
+    int B, cs;
+    long long tm0_w, tm0_b, tm2_w, tm2_b;
+    long long mlp_w[4], mlp_b[4], tr_w[4], tr_b[4];
+    int cin[4], coff[4];
+};
+
+__global__ __launch_bounds__(512) void cond_backward_kernel(CondBwdArgs a) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float* P = a.params;
+    float* G = a.grads;
+    const int B = a.B;
+    // P1: dm = dcond . Wtr ; grads of time_reshape
+    for (int it = tid; it < B * 128; it += nt) {
+        const int b = it >> 7, l = (it >> 5) & 3, k = it & 31;
+        const float* dc = a.dcond + (size_t)b * a.cs + a.coff[l];
+        const float* w = P + a.tr_w[l] + k;
+        float s = 0.f;
+        for (int c = 0; c < a.cin[l]; ++c) s = fmaf(dc[c], w[(size_t)c * 32], s);
+        a.dm[it] = s;
+    }
+    for (int l = 0; l < 4; ++l) {
+        for (int it = tid; it < a.cin[l] * 32; it += nt) {
+            const int c = it >> 5, k = it & 31;
+            float s = 0.f;
+            for (int b = 0; b < B; ++b)
+                s = fmaf(a.dcond[(size_t)b * a.cs + a.coff[l] + c], a.mvec[((size_t)b * 4 + l) * 32 + k], s);
+            G[a.tr_w[l] + it] += s;
+        }
+        for (int c = tid; c < a.cin[l]; c += nt) {
+            float s = 0.f;
+            for (int b = 0; b < B; ++b) s += a.dcond[(size_t)b * a.cs + a.coff[l] + c];
+            G[a.tr_b[l] + c] += s;
+        }
+    }
+    __syncthreads();
+    // P2: through the per-block Linear(32,32) and GELU(cond)
+    for (int it = tid; it < B * 32; it += nt) {
+        const int b = it >> 5, k = it & 31;
+        float s = 0.f;
+        for (int l = 0; l < 4; ++l) {
+            const float* w = P + a.mlp_w[l] + k;
+            const float* d = a.dm + ((size_t)b * 4 + l) * 32;
+            for (int j = 0; j < 32; ++j) s = fmaf(d[j], w[j * 32], s);
+        }
+        a.dcv[it] = s * gelu_erf_grad(a.cvec[it]);
+    }
+    for (int it = tid; it < 4 * 1024; it += nt) {
+        const int l = it >> 10, j = (it >> 5) & 31, k = it & 31;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a.dm[((size_t)b * 4 + l) * 32 + j], gelu_erf(a.cvec[b * 32 + k]), s);
+        G[a.mlp_w[l] + j * 32 + k] += s;
+    }
+    for (int it = tid; it < 128; it += nt) {
+        const int l = it >> 5, j = it & 31;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += a.dm[((size_t)b * 4 + l) * 32 + j];
+        G[a.mlp_b[l] + j] += s;
+    }
+    __syncthreads();
+    // P3: time_mlp.2 (32 x 128) and the GELU before it
+    for (int it = tid; it < B * 128; it += nt) {
+        const int b = it >> 7, j = it & 127;
+        float s = 0.f;
+        for (int k = 0; k < 32; ++k) s = fmaf(a.dcv[b * 32 + k], P[a.tm2_w + k * 128 + j], s);
+        a.dh1[it] = s * gelu_erf_grad(a.hpre[it]);
+    }
+    for (int it = tid; it < 32 * 128; it += nt) {
+        const int k = it >> 7, j = it & 127;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a.dcv[b * 32 + k], gelu_erf(a.hpre[b * 128 + j]), s);
+        G[a.tm2_w + it] += s;
+    }
+    for (int k = tid; k < 32; k += nt) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += a.dcv[b * 32 + k];
+        G[a.tm2_b + k] += s;
+    }
+    __syncthreads();
+    // P4: time_mlp.0 (128 x 64)
+    for (int it = tid; it < 128 * 64; it += nt) {
+        const int j = it >> 6, i = it & 63;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a.dh1[b * 128 + j], a.emb[b * 64 + i], s);
+        G[a.tm0_w + it] += s;
+    }
+    for (int j = tid; j < 128; j += nt) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += a.dh1[b * 128 + j];
+        G[a.tm0_b + j] += s;
+    }
+}
+
+// =====================================================================================
+// L1 loss forward+backward, fused Adam / EMA
+// =====================================================================================
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ noise, const float* __restrict__ eps,
+                                                      float* __restrict__ loss, float* __restrict__ grad, long long n,
+                                                      float inv_n, float gscale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float d = noise[i] - eps[i];
+        s += fabsf(d);
+        // d|noise-eps|/d eps = -sign(noise-eps), sign(0) = 0   (reference SinDDM/models.py:594)
+        if (grad) grad[i] = (d > 0.f ? -1.f : (d < 0.f ? 1.f : 0.f)) * inv_n * gscale;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, ((red[0] + red[1]) + (red[2] + red[3])) * inv_n);
+}
+
+__global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       float* __restrict__ ema, float step_size, float b1, float b2,
+                                                       float eps, float bc2_sqrt, float ema_decay, int mode,
+                                                       long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float pv = p[i];
+        if (mode & 1) {
+            // torch.optim.Adam (no wd, no amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+            // p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps),  step_size = lr / bc1
+            const float gv = g[i];
+            const float mv = b1 * m[i] + (1.f - b1) * gv;
+            const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+            m[i] = mv;
+            v[i] = vv;
+            pv = pv - step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+            p[i] = pv;
+        }
+        if (mode & 2) ema[i] = pv;                                             // copy phase (step < step_start_ema)
+        else if (mode & 4) ema[i] = ema[i] * ema_decay + (1.f - ema_decay) * pv;   // models.py:28-31
+    }
+}
+
+// =====================================================================================
+// packed images for the data-gradient convolutions
+// =====================================================================================
+struct BwdPack {
+    // per block: dgrad of conv2 (cout->cout), dgrad of conv1 (cout->cin), dgrad of res 1x1 (cout->cin)
+    long long dg2[4], dg1[4], dres[4], dfin;
+    long long total;
+    int mt2[4], mt1[4], cb2[4], cb1[4];
+    int mtf, cbf;
+};
+
+static BwdPack make_bwd_pack(const NetPlan& P) {
+    BwdPack k{};
+    long long q = 0;
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        k.mt2[l] = mt_for(b.cout); k.cb2[l] = (b.cout + k.mt2[l] * 16 - 1) / (k.mt2[l] * 16);
+        k.mt1[l] = mt_for(b.cin);  k.cb1[l] = (b.cin + k.mt1[l] * 16 - 1) / (k.mt1[l] * 16);
+        const int nchK = (b.cout + KC - 1) / KC;      // K channels of every dgrad = forward cout
+        k.dg2[l] = q; q += (long long)k.cb2[l] * nchK * 9 * KC * co_lds_for(k.mt2[l]);
+        k.dg1[l] = q; q += (long long)k.cb1[l] * nchK * 9 * KC * co_lds_for(k.mt1[l]);
+        if (b.res_w >= 0) { k.dres[l] = q; q += (long long)k.cb1[l] * nchK * KC * co_lds_for(k.mt1[l]); }
+        else k.dres[l] = -1;
+    }
+    k.mtf = mt_for(P.half); k.cbf = (P.half + k.mtf * 16 - 1) / (k.mtf * 16);
+    k.dfin = q; q += (long long)k.cbf * 1 * KC * co_lds_for(k.mtf);     // K = 3 channels -> one chunk
+    k.total = q;
+    return k;
+}
+
+static int pack_backward(const NetPlan& P, const float* params, float* packed, hipStream_t st) {
+    const BwdPack k = make_bwd_pack(P);
+    PackArgs a{};
+    int n = 0;
+    long long total = 0;
+    auto add = [&](long long dst, long long w, int fcin, int fcout, int taps, int mt, int coblks) {
+        PackSeg s{};
+        s.kind = 0; s.transpose = 1; s.w2 = -1;
+        s.dst = dst; s.w = w; s.cin = fcin; s.cout = fcout; s.taps = taps; s.mt = mt; s.co_lds = co_lds_for(mt);
+        s.nch = (fcout + KC - 1) / KC;
+        s.count = (long long)coblks * s.nch * taps * KC * s.co_lds;
+        a.seg[n++] = s;
+        total += s.count;
+    };
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        add(k.dg2[l], b.c2_w, b.cout, b.cout, 9, k.mt2[l], k.cb2[l]);
+        add(k.dg1[l], b.c1_w, b.cin, b.cout, 9, k.mt1[l], k.cb1[l]);
+        if (b.res_w >= 0) add(k.dres[l], b.res_w, b.cin, b.cout, 1, k.mt1[l], k.cb1[l]);
+    }
+    add(k.dfin, P.fin_w, P.half, CHANNELS, 1, k.mtf, k.cbf);
+    a.nseg = n;
+    a.total = total;
+    // segments are laid out back to back in `packed` in the same order -> dst offsets are cumulative
+    return pack_launch(params, packed, a, st);
+}
+
+// =====================================================================================
+// training workspace
+// =====================================================================================
+static size_t au(size_t v) { return (v + 255) / 256 * 256; }
+
+static size_t carve_train(const NetPlan& P, int B, int H, int W, char* base, TrainBufs* tb) {
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += au(nfloats * sizeof(float));
+        return p;
+    };
+    const size_t HW = (size_t)H * W;
+    TrainBufs t{};
+    t.cond = take((size_t)B * P.cond_stride);
+    t.emb = take((size_t)B * 64);
+    t.hpre = take((size_t)B * 128);
+    t.cvec = take((size_t)B * 32);
+    t.mvec = take((size_t)B * 128);
+    for (int l = 0; l < 4; ++l) {
+        t.h[l] = take((size_t)B * P.blk[l].cin * HW);
+        t.u[l] = take((size_t)B * P.blk[l].cout * HW);
+        t.g[l] = take((size_t)B * P.blk[l].cout * HW);
+        t.o[l] = take((size_t)B * P.blk[l].cout * HW);
+    }
+    for (int i = 0; i < 4; ++i) t.s[i] = take((size_t)B * P.dim * HW);
+    t.dcond = take((size_t)B * P.cond_stride);
+    t.small = take((size_t)B * (128 + 32 + 128));
+    if (tb) *tb = t;
+    return off;
+}
+
+static int conv1x1_or_3x3(const float* in3, int cin3, const float* w3, int nch3, const float* in1, int cin1,
+                          const float* w1, int nch1, const float* aux, int act, float* out, int Cout, int mt, int coblks,
+                          int B, int H, int W, hipStream_t st) {
+    ConvArgs c{};
+    c.in = in3; c.Cin = cin3; c.w3 = w3; c.nch3 = nch3;
+    c.in2 = in1; c.Cin2 = cin1; c.w1 = w1; c.nch1 = nch1;
+    c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
+    c.B = B; c.H = H; c.W = W;
+    return conv_launch(c, mt, st);
+}
+
+static int net_backward_impl(const NetPlan& P, const float* params, const float* packed_bwd, const float* x,
+                             const float* grad_out, float* grads, float* grad_x, int B, int H, int W,
+                             const TrainBufs& tb, hipStream_t st) {
+    const BwdPack k = make_bwd_pack(P);
+    int rc;
+    // ---- final 1x1 conv: weight/bias grads, then data grad into s[0] ----
+    rc = wgrad_launch(grad_out, tb.o[3], grads + P.fin_w, grads + P.fin_b, B, H, W, P.half, CHANNELS, 1, st);
+    if (rc) return rc;
+    int di = 0;   // index of the scratch buffer holding dOut of the current block
+    rc = conv1x1_or_3x3(nullptr, 0, nullptr, 0, grad_out, CHANNELS, packed_bwd + k.dfin, 1, nullptr, 0, tb.s[di],
+                        P.half, k.mtf, k.cbf, B, H, W, st);
+    if (rc) return rc;
+    for (int l = 3; l >= 0; --l) {
+        const BlockPlan& b = P.blk[l];
+        const float* xin = (l == 0) ? x : tb.o[l - 1];
+        float* dO = tb.s[di];
+        float* dU = tb.s[(di + 1) & 3];
+        float* dH = tb.s[(di + 2) & 3];
+        float* dX = tb.s[(di + 3) & 3];
+        const int nchK = (b.cout + KC - 1) / KC;
+        // conv2 + residual projection weight grads
+        rc = wgrad_launch(dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st);
+        if (rc) return rc;
+        if (b.res_w >= 0) {
+            rc = wgrad_launch(dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
+            if (rc) return rc;
+        }
+        // dU = dgrad_conv2(dO) * GELU'(u)
+        rc = conv1x1_or_3x3(dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU, b.cout,
+                            k.mt2[l], k.cb2[l], B, H, W, st);
+        if (rc) return rc;
+        // conv1 weight grads, dH = dgrad_conv1(dU)
+        rc = wgrad_launch(dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
+        if (rc) return rc;
+        rc = conv1x1_or_3x3(dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH, b.cin,
+                            k.mt1[l], k.cb1[l], B, H, W, st);
+        if (rc) return rc;
+        // depthwise weight/bias grads and the per-sample condition grads
+        hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
+                           grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
+        SINDDM_LAUNCH_CHECK();
+        // data grad w.r.t. the block input: dw^T(dH) + residual path
+        if (l > 0 || grad_x) {
+            const float* radd = dO;                      // identity residual
+            if (b.res_w >= 0) {
+                rc = conv1x1_or_3x3(nullptr, 0, nullptr, 0, dO, b.cout, packed_bwd + k.dres[l], nchK, nullptr, 0, dU,
+                                    b.cin, k.mt1[l], k.cb1[l], B, H, W, st);     // dU is free again
+                if (rc) return rc;
+                radd = dU;
+            }
+            float* dst = (l == 0) ? grad_x : dX;
+            rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st);
+            if (rc) return rc;
+            di = (di + 3) & 3;
+        }
+    }
+    // ---- conditioning path ----
+    CondBwdArgs ca{};
+    ca.params = params; ca.grads = grads; ca.dcond = tb.dcond; ca.emb = tb.emb; ca.hpre = tb.hpre; ca.cvec = tb.cvec;
+    ca.mvec = tb.mvec; ca.dm = tb.small; ca.dcv = tb.small + (size_t)B * 128; ca.dh1 = tb.small + (size_t)B * 160;
+    ca.B = B; ca.cs = P.cond_stride;
+    ca.tm0_w = P.tm0_w; ca.tm0_b = P.tm0_b; ca.tm2_w = P.tm2_w; ca.tm2_b = P.tm2_b;
+    for (int l = 0; l < 4; ++l) {
+        ca.mlp_w[l] = P.blk[l].mlp_w; ca.mlp_b[l] = P.blk[l].mlp_b; ca.tr_w[l] = P.blk[l].tr_w; ca.tr_b[l] = P.blk[l].tr_b;
+        ca.cin[l] = P.blk[l].cin; ca.coff[l] = P.blk[l].cond_off;
+    }
+    hipLaunchKernelGGL(cond_backward_kernel, dim3(1), dim3(512), 0, st, ca);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sinddm
+
+using namespace sinddm;
+
+extern "C" {
+
+size_t sinddm_train_workspace_bytes(int dim, int B, int H, int W) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || B <= 0 || H <= 0 || W <= 0) return 0;
+    return carve_train(p, B, H, W, nullptr, nullptr);
+}
+
+int64_t sinddm_packed_bwd_count(int dim) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return -1;
+    return make_bwd_pack(p).total;
+}
+
+int sinddm_pack_weights_bwd(const float* params, float* packed_bwd, int dim, void* stream) {
+    if (!params || !packed_bwd) return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    return pack_backward(p, params, packed_bwd, static_cast<hipStream_t>(stream));
+}
+
+int sinddm_net_forward_train(const float* params, const float* packed, const float* x, const int64_t* t_dev,
+                             int t_host, float scale, float* out, int dim, int B, int H, int W, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!params || !packed || !x || !out || !ws || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    TrainBufs tb;
+    if (carve_train(p, B, H, W, static_cast<char*>(ws), &tb) > ws_bytes) return SINDDM_E_WORKSPACE;
+    return net_forward_impl(p, params, packed, x, t_dev, t_host, scale, out, B, H, W, nullptr, 0,
+                            static_cast<hipStream_t>(stream), &tb);
+}
+
+int sinddm_net_backward(const float* params, const float* packed, const float* packed_bwd, const float* x,
+                        const float* grad_out, float* grad_params, float* grad_x, int dim, int B, int H, int W,
+                        void* ws, size_t ws_bytes, void* stream) {
+    (void)packed;
+    if (!params || !packed_bwd || !x || !grad_out || !grad_params || !ws || B <= 0 || H <= 0 || W <= 0)
+        return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    TrainBufs tb;
+    if (carve_train(p, B, H, W, static_cast<char*>(ws), &tb) > ws_bytes) return SINDDM_E_WORKSPACE;
+    return net_backward_impl(p, params, packed_bwd, x, grad_out, grad_params, grad_x, B, H, W, tb,
+                             static_cast<hipStream_t>(stream));
+}
+
+int sinddm_l1_loss_fwd_bwd(const float* noise, const float* eps, float* loss_out, float* grad_out, int64_t n,
+                           float grad_scale, void* stream) {
+    if (!noise || !eps || !loss_out || n <= 0) return SINDDM_E_BADARG;
+    long long bx = (n + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), noise, eps,
+                       loss_out, grad_out, (long long)n, 1.0f / (float)n, grad_scale);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, float step_size, float beta1,
+                         float beta2, float eps, float bc2_sqrt, float ema_decay, float reserved, int mode, int64_t n,
+                         void* stream) {
+    (void)reserved;
+    if (!p || n <= 0) return SINDDM_E_BADARG;
+    if ((mode & 1) && (!g || !m || !v)) return SINDDM_E_BADARG;
+    if ((mode & 6) && !ema) return SINDDM_E_BADARG;
+    long long bx = (n + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
+                       ema, step_size, beta1, beta2, eps, bc2_sqrt, ema_decay, mode, (long long)n);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

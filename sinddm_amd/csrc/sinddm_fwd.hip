@@ -1,6 +1,7 @@
 // Forward path of the SinDDM hot path for gfx950: weight packing, conditioning MLP, depthwise
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
+#include "internal.h"
 
 namespace sinddm {
 
@@ -12,21 +13,6 @@ ConvProfiler& conv_profiler() {
 // =====================================================================================
 // weight packing: flat nn.Module-order parameters -> MFMA chunk images
 // =====================================================================================
-struct PackSeg {
-    long long dst;     // offset in packed
-    long long count;   // elements in this segment
-    long long w;       // source weight offset (conv: [cout][cin][taps]), or bias offset
-    long long w2;      // second bias offset to add (-1 none)
-    int kind;          // 0: conv chunks, 1: bias
-    int cin, cout, taps, nch, mt, co_lds;
-    int transpose;     // 1: dgrad image (M = cin of the forward conv, taps flipped)
-};
-struct PackArgs {
-    PackSeg seg[24];
-    int nseg;
-    long long total;
-};
-
 __global__ void pack_kernel(const float* __restrict__ params, float* __restrict__ packed, PackArgs a) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.total) return;
@@ -64,6 +50,14 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
     packed[g.dst + j] = v;
 }
 
+int pack_launch(const float* params, float* packed, const PackArgs& a, hipStream_t st) {
+    const int threads = 256;
+    const unsigned grid = (unsigned)((a.total + threads - 1) / threads);
+    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(threads), 0, st, params, packed, a);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
 static int pack_forward(const NetPlan& P, const float* params, float* packed, hipStream_t st) {
     PackArgs a{};
     int n = 0;
@@ -95,11 +89,7 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
     }
     a.nseg = n;
     a.total = total;
-    const int threads = 256;
-    const unsigned grid = (unsigned)((total + threads - 1) / threads);
-    hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(threads), 0, st, params, packed, a);
-    SINDDM_LAUNCH_CHECK();
-    return 0;
+    return pack_launch(params, packed, a, st);
 }
 
 // =====================================================================================
@@ -118,6 +108,8 @@ struct CondArgs {
     int cin[4], coff[4];
     float* cond_vec;     // optional [B][32] raw cond vector (saved for backward), may be null
     float* hidden;       // optional [B][128] pre-GELU hidden of time_mlp (saved for backward)
+    float* emb_out;      // optional [B][64] sinusoidal embedding
+    float* mvec_out;     // optional [B][4][32] per-block mlp outputs
 };
 
 __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
@@ -142,6 +134,7 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
         emb[o + 16 + i] = cosf(arg);
     }
     __syncthreads();
+    if (a.emb_out && tid < 64) a.emb_out[(long long)b * 64 + tid] = emb[tid];
     {
         float s = P[a.tm0_b + tid];
         const float* w = P + a.tm0_w + (long long)tid * 64;
@@ -168,6 +161,7 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
 #pragma unroll 8
             for (int k = 0; k < 32; ++k) s = fmaf(w[k], gv[k], s);
             mv[tid] = s;
+            if (a.mvec_out) a.mvec_out[((long long)b * 4 + l) * 32 + tid] = s;
         }
         __syncthreads();
         for (int c = tid; c < a.cin[l]; c += blockDim.x) {
@@ -190,8 +184,8 @@ constexpr int DW_TH = 16, DW_TW = 64, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
 
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
-                                                       int cond_stride, float* __restrict__ out, int C, int H, int W,
-                                                       int tilesX) {
+                                                       int cond_stride, const float* __restrict__ addt, int flip,
+                                                       float* __restrict__ out, int C, int H, int W, int tilesX) {
     __shared__ __attribute__((aligned(16))) float tile[DW_HR * DW_RS];
     const int c = blockIdx.y, b = blockIdx.z;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
@@ -204,8 +198,8 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     }
     float wk[25];
 #pragma unroll
-    for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + k];
-    const float add = bias[c] + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
+    for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + (flip ? 24 - k : k)];   // flip -> transposed conv (data grad)
+    const float add = (bias ? bias[c] : 0.0f) + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
     __syncthreads();
     const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
     float o0 = add, o1 = add, o2 = add, o3 = add;
@@ -225,8 +219,16 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     }
     const int gy = y0 + r;
     if (gy < H) {
-        float* dst = out + (((size_t)b * C + c) * H + gy) * W;
+        const size_t rowo = (((size_t)b * C + c) * H + gy) * W;
+        float* dst = out + rowo;
         const int gx = x0 + xg * 4;
+        if (addt) {
+            const float* as = addt + rowo;
+            if (gx < W) o0 += as[gx];
+            if (gx + 1 < W) o1 += as[gx + 1];
+            if (gx + 2 < W) o2 += as[gx + 2];
+            if (gx + 3 < W) o3 += as[gx + 3];
+        }
         if (gx < W) dst[gx] = o0;
         if (gx + 1 < W) dst[gx + 1] = o1;
         if (gx + 2 < W) dst[gx + 2] = o2;
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     }
 }
 
-int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride, float* out,
-                  int B, int C, int H, int W, hipStream_t st) {
+int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
+                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st) {
     const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
     hipLaunchKernelGGL(dwconv5_kernel, dim3(tilesX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                       out, C, H, W, tilesX);
+                       addt, flip, out, C, H, W, tilesX);
     SINDDM_LAUNCH_CHECK();
     return 0;
 }
@@ -354,14 +356,18 @@ static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
 
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
-                     hipStream_t st) {
-    if (ws_bytes < fwd_workspace_bytes(P, B, H, W)) return SINDDM_E_WORKSPACE;
-    char* base = static_cast<char*>(ws);
-    FwdBuffers fb;
-    fb.cond = reinterpret_cast<float*>(base);
-    base += align_up((size_t)B * P.cond_stride * sizeof(float), 256);
-    const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
-    for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
+                     hipStream_t st, const TrainBufs* tb) {
+    FwdBuffers fb{};
+    if (tb) {
+        fb.cond = tb->cond;
+    } else {
+        if (ws_bytes < fwd_workspace_bytes(P, B, H, W)) return SINDDM_E_WORKSPACE;
+        char* base = static_cast<char*>(ws);
+        fb.cond = reinterpret_cast<float*>(base);
+        base += align_up((size_t)B * P.cond_stride * sizeof(float), 256);
+        const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
+        for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
+    }
 
     CondArgs ca{};
     ca.params = params; ca.t_dev = reinterpret_cast<const long long*>(t_dev); ca.t_host = t_host; ca.scale = scale;
@@ -372,7 +378,8 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         ca.tr_w[l] = P.blk[l].tr_w; ca.tr_b[l] = P.blk[l].tr_b;
         ca.cin[l] = P.blk[l].cin; ca.coff[l] = P.blk[l].cond_off;
     }
-    ca.cond_vec = nullptr; ca.hidden = nullptr;
+    ca.cond_vec = tb ? tb->cvec : nullptr; ca.hidden = tb ? tb->hpre : nullptr;
+    ca.emb_out = tb ? tb->emb : nullptr; ca.mvec_out = tb ? tb->mvec : nullptr;
     hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(128), 0, st, ca);
     SINDDM_LAUNCH_CHECK();
 
@@ -385,16 +392,17 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         int sel[3], n = 0;
         for (int i = 0; i < 4 && n < 3; ++i)
             if (freeb[i] != curb) sel[n++] = freeb[i];
-        float* hbuf = fb.buf[sel[0]];
-        float* gbuf = fb.buf[sel[1]];
-        float* obuf = fb.buf[sel[2]];
-        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, P.cond_stride, hbuf, B,
-                               b.cin, H, W, st);
+        float* hbuf = tb ? tb->h[l] : fb.buf[sel[0]];
+        float* gbuf = tb ? tb->g[l] : fb.buf[sel[1]];
+        float* obuf = tb ? tb->o[l] : fb.buf[sel[2]];
+        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, P.cond_stride, nullptr, 0,
+                               hbuf, B, b.cin, H, W, st);
         if (rc) return rc;
         ConvArgs c1{};
         c1.in = hbuf; c1.w3 = packed + b.pk_c1; c1.bias = packed + b.pk_b1; c1.out = gbuf;
         c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch3 = b.nch1; c1.nch1 = 0;
         c1.coblks = b.coblks; c1.act = 1;
+        c1.out_pre = tb ? tb->u[l] : nullptr;
         rc = conv_launch(c1, b.mt, st);
         if (rc) return rc;
         ConvArgs c2{};
@@ -455,7 +463,7 @@ int sinddm_net_forward(const float* params, const float* packed, const float* x,
     NetPlan p = make_plan(dim);
     if (!p.ok) return SINDDM_E_BADSHAPE;
     return net_forward_impl(p, params, packed, x, t_dev, t_host, scale, out, B, H, W, ws, ws_bytes,
-                            static_cast<hipStream_t>(stream));
+                            static_cast<hipStream_t>(stream), nullptr);
 }
 
 int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, float* out, const float* tab_sqrt_ac,

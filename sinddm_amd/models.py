@@ -204,7 +204,7 @@ class SinDDMNet(nn.Module):
         """Call after the parameters were changed through raw pointers (fused optimizer)."""
         self._dirty += 1
 
-    def _version(self) -> int:
+    def _param_version(self) -> int:
         # in-place updates through the nn.Parameter views (load_state_dict, torch optimizers) bump the
         # parameters' own version counters; raw-pointer updates call mark_dirty()
         return sum(p._version for p in self.parameters()) + (self._dirty << 32)
@@ -230,7 +230,7 @@ class SinDDMNet(nn.Module):
     def packed_weights(self) -> torch.Tensor:
         """MFMA-ready weight image; rebuilt on device whenever the parameters changed."""
         lib = _lib.load()
-        v = self._version()
+        v = self._param_version()
         if self._packed is None or self._packed_version != v:
             if self._packed is None:
                 self._check_lib_layout()
@@ -243,7 +243,7 @@ class SinDDMNet(nn.Module):
 
     def packed_weights_bwd(self) -> torch.Tensor:
         lib = _lib.load()
-        v = self._version()
+        v = self._param_version()
         if self._packed_bwd is None or self._packed_bwd_version != v:
             if self._packed_bwd is None:
                 self._packed_bwd = torch.empty(lib.sinddm_packed_bwd_count(self.dim), dtype=torch.float32,

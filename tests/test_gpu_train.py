@@ -1,0 +1,183 @@
+"""GPU parity tests of the training path: HIP forward-with-save + backward + L1 loss + fused Adam/EMA
+(through the C ABI) vs golden fixtures from the reference and vs the CPU oracle's autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import max_abs, rel_l2
+from oracle import sinddm_oracle as O
+from sinddm_amd.synth import closed_form_state_dict, hash_randn, noise_key
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pyr_tensor(arr):
+    return torch.from_numpy(arr.transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)
+
+
+def _diffusion(golden, dim):
+    from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
+    meta = golden("g11_img_scales.json")["C1"]
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    d = MultiScaleGaussianDiffusion(net, n_scales=meta["n_scales"], scale_factor=meta["scale_factor"],
+                                    image_sizes=[tuple(s) for s in meta["sizes"]], timesteps=meta["T"],
+                                    train_full_t=True, scale_losses=meta["rescale_losses"], loss_factor=1,
+                                    loss_type="l1", device=DEV, reblurring=True, omega=0).to(DEV)
+    return net, d, meta
+
+
+def test_l1_loss_kernel():
+    from sinddm_amd.autograd import l1_loss
+    a = hash_randn((3, 3, 37, 41), 1).to(DEV)
+    b = hash_randn((3, 3, 37, 41), 2).to(DEV).requires_grad_(True)
+    b.data[0, 0, 0, :5] = a[0, 0, 0, :5]          # exact ties -> sign(0) = 0
+    loss = l1_loss(a, b)
+    (loss * 0.5).backward()
+    bc = b.detach().cpu().requires_grad_(True)
+    ref = (a.cpu() - bc).abs().mean()
+    (ref * 0.5).backward()
+    assert abs(float(loss) - float(ref)) < 1e-6
+    assert max_abs(b.grad.cpu(), bc.grad) < 1e-9
+
+
+def test_adam_ema_kernels():
+    from sinddm_amd.models import SinDDMNet
+    from sinddm_amd.optim import FusedAdam, ema_update_
+    net = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    ema = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    ema.load_state_dict(net.state_dict())
+    opt = FusedAdam(net, lr=1e-3)
+    p = net.flat_params.detach().cpu().clone()
+    e = p.clone()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for n in range(1, 6):
+        g = hash_randn(tuple(p.shape), 100 + n) * (10.0 ** (n - 3))
+        net.flat_grads.copy_(g.to(DEV))
+        lr = O.multistep_lr(1e-3, [2, 4], n)
+        opt.param_groups[0]["lr"] = lr
+        opt.step()
+        O.adam_step(p, g, m, v, n, lr)
+        assert max_abs(net.flat_params.cpu(), p) < 2e-7, n
+        ema_update_(ema, net, 0.995)
+        e = O.ema_update(e, p, 0.995)
+        assert max_abs(ema.flat_params.cpu(), e) < 2e-7, n
+    # parameters seen through the nn.Parameter views are the updated ones
+    assert max_abs(torch.cat([q.detach().reshape(-1) for q in net.parameters()]).cpu(), p) < 2e-7
+
+
+@pytest.mark.parametrize("s", [0, 2])
+def test_p_losses_grads_golden(golden, s):
+    """G5: loss value and all 52 parameter gradients of p_losses vs the reference (dim=32, B=2)."""
+    g5 = golden("g5_losses.npz")
+    pyr = golden("c1_pyramid.npz")
+    net, d, meta = _diffusion(golden, 32)
+    net.bind_grads()
+    net.flat_grads.zero_()
+    orig = _pyr_tensor(pyr[f"scale_{s}"])[None].repeat(2, 1, 1, 1).to(DEV)
+    recon = _pyr_tensor(pyr[f"scale_{s}_recon"])[None].repeat(2, 1, 1, 1).to(DEV) if s > 0 else orig
+    t = torch.tensor([37, 5], device=DEV)
+    noise = hash_randn(tuple(orig.shape), noise_key("train", s, 0)).to(DEV)
+    if s > 0:
+        loss = d.p_losses(recon, t, s, noise=noise, x_orig=orig)
+    else:
+        loss = d.p_losses(orig, t, s, noise=noise)
+    loss.backward()
+    assert abs(float(loss) - float(g5[f"s{s}_loss"])) < 2e-6
+    worst = 0.0
+    for name, p in net.named_parameters():
+        ref = g5[f"s{s}_g_{name}"]
+        err = rel_l2(p.grad.cpu(), ref)
+        worst = max(worst, err)
+        assert err < 2e-4, (name, err)
+    print("worst rel-l2 grad error", worst)
+
+
+@pytest.mark.parametrize("dim,B,H,W", [(160, 2, 21, 37), (160, 1, 40, 70), (32, 3, 9, 33), (16, 1, 5, 7)])
+def test_net_backward_vs_oracle_autograd(dim, B, H, W):
+    """Parameter gradients AND input gradient vs torch autograd through the CPU oracle (ragged sizes)."""
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    net.bind_grads()
+    net.flat_grads.zero_()
+    x = hash_randn((B, 3, H, W), 5)
+    gy = hash_randn((B, 3, H, W), 6)
+    t = torch.arange(B) * 11 + 3
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd, t.to(DEV), scale=2)
+    y.backward(gy.to(DEV))
+    sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
+    xc = x.clone().requires_grad_(True)
+    yc = O.net_forward(sd, xc, t, 2)
+    yc.backward(gy)
+    assert rel_l2(y.detach().cpu(), yc.detach()) < 1e-5
+    assert rel_l2(xd.grad.cpu(), xc.grad) < 5e-5
+    for name, p in net.named_parameters():
+        err = rel_l2(p.grad.cpu(), sd[name].grad)
+        assert err < 2e-4, (name, err)
+    # gradients accumulate (+=) like autograd: a second backward doubles them
+    y2 = net(x.to(DEV), t.to(DEV), scale=2)
+    y2.backward(gy.to(DEV))
+    for name, p in net.named_parameters():
+        assert rel_l2(p.grad.cpu(), 2 * sd[name].grad) < 2e-4, name
+
+
+def test_train_20_steps_golden(golden, tmp_path):
+    """G10: 20 optimizer steps of MultiscaleTrainer.train() with injected (scale, t, noise): loss
+    trajectory, LR schedule, final parameters and EMA parameters vs the reference run."""
+    from sinddm_amd.trainer import MultiscaleTrainer
+    g = golden("g10_train.npz")
+    pyr = golden("c1_pyramid.npz")
+    folder = str(tmp_path / "balloons") + "/"
+    for key in pyr.files:
+        os.makedirs(folder + key, exist_ok=True)
+        Image.fromarray(pyr[key]).save(folder + key + "/balloons.png")
+    net, d, meta = _diffusion(golden, 32)
+    sizes = [tuple(s) for s in meta["sizes"]]
+    tr = MultiscaleTrainer(d, folder=folder, n_scales=meta["n_scales"], scale_factor=meta["scale_factor"],
+                           image_sizes=sizes, train_batch_size=2, train_lr=1e-3, train_num_steps=20,
+                           gradient_accumulate_every=1, ema_decay=0.995, fp16=False, step_start_ema=6,
+                           update_ema_every=2, save_and_sample_every=10 ** 9, avg_window=100,
+                           sched_milestones=[5, 12], results_folder=str(tmp_path / "res"), device=DEV)
+    s_seq, t_seq = list(g["s_seq"]), g["t_seq"]
+    tr.scale_fn = lambda step: s_seq[step]
+    losses, lrs = [], []
+    orig_forward = d.forward
+
+    def rec_forward(x, s, *a, **k):
+        loss = orig_forward(x, s, *a, **k)
+        losses.append(loss.detach())
+        lrs.append(tr.opt.param_groups[0]["lr"])
+        return loss
+
+    d.forward = rec_forward
+    o_randint, o_randn_like = torch.randint, torch.randn_like
+    torch.randint = lambda lo, hi, size, **kw: torch.tensor(t_seq[tr.step], dtype=torch.long, device=DEV)
+    torch.randn_like = lambda x, **kw: hash_randn(tuple(x.shape), noise_key("train", s_seq[tr.step], tr.step)).to(x.device)
+    try:
+        tr.train()
+    finally:
+        torch.randint, torch.randn_like = o_randint, o_randn_like
+    losses = np.array([float(l) for l in losses])
+    assert np.allclose(np.array(lrs), g["lrs"], rtol=0, atol=1e-12)
+    # the first step is identical to fp32 rounding; later steps drift slowly because Adam's update is
+    # sign-like for small gradients (the same happens between two BLAS back-ends of the reference)
+    assert abs(losses[0] - g["losses"][0]) < 2e-6
+    assert (np.abs(losses - g["losses"]) / g["losses"]).max() < 2e-3, np.abs(losses - g["losses"]) / g["losses"]
+    # Adam's m/sqrt(v) is sign-like for tiny gradients, so individual weights may differ by O(lr);
+    # compare the parameter vectors as a whole
+    pv = torch.cat([p.detach().reshape(-1) for p in tr.model.denoise_fn.parameters()]).cpu()
+    ev = torch.cat([p.detach().reshape(-1) for p in tr.ema_model.denoise_fn.parameters()]).cpu()
+    names = [n for n, _ in tr.model.denoise_fn.named_parameters()]
+    rp = torch.cat([torch.from_numpy(g[f"p_{n}"]).reshape(-1) for n in names])
+    re = torch.cat([torch.from_numpy(g[f"ema_{n}"]).reshape(-1) for n in names])
+    p0 = torch.cat([v.reshape(-1) for v in closed_form_state_dict(32).values()])
+    # relative to the distance actually travelled by the optimizer
+    moved = float((rp - p0).norm())
+    assert float((pv - rp).norm()) / moved < 2e-2, float((pv - rp).norm()) / moved
+    assert float((ev - re).norm()) / float((re - p0).norm()) < 2e-2
