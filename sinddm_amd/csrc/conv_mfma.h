@@ -5,18 +5,21 @@
 //
 // GEMM view: M = C_out (16-row tiles), N = pixels (16 consecutive pixels of one image row per
 // tile), K = (ci, tap).  Instruction: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, 157 TF/s
-// chip peak).  A workgroup = 4 waves owns an 8x32 pixel tile for MT*16 output channels; each
-// wave owns MT x 4 accumulator tiles (MT*16 channels x 64 pixels).  K is walked in chunks of
+// chip peak).  A workgroup = 4 waves owns a (TH x 32) pixel tile for MT*16 output channels; each
+// wave owns MT x NT accumulator tiles (MT*16 channels x NT*16 pixels).  K is walked in chunks of
 // KC=8 input channels: the chunk's weights ([tap][ci][co], pre-packed so the copy is linear
-// float4) and the chunk's input halo tile (10x34 per channel) are staged in LDS; the loads of
+// float4) and the chunk's input halo tile ((TH+2) x 34 per channel) are staged in LDS; the loads of
 // chunk c+1 are issued into registers before the MFMAs of chunk c so their latency hides under
 // compute.  LDS strides are chosen == 16 (mod 32) so both operand reads are bank-conflict-free.
+// Inside a chunk the A/B fragments of k-step i+1 are read from LDS before the MFMAs of k-step i
+// (register double buffering), so the matrix pipe never waits on an LDS round trip.
 //
 // This replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] and
 // nn.Conv2d(dim_out, dim_out, 3, padding=1) + res_conv(x) of SinDDMConvBlock
 // (reference SinDDM/models.py:63-67,79-80); with transposed/flipped packed weights the same
 // kernel is the data-gradient of those convolutions.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 namespace sinddm {
@@ -29,6 +32,7 @@ struct ConvArgs {
     const float* w3;     // packed [coblk][chunk][9][KC][CO_LDS]
     const float* w1;     // packed [coblk][chunk][KC][CO_LDS]
     const float* bias;   // packed [coblk][MT*16] or nullptr
+    const float* zero;   // >= 64 zero floats (tail of the packed image): source of LDS-DMA zero fill
     float* out;          // [B][Cout][H][W]
     float* out_pre;      // optional: pre-activation (value before GELU) for training, or nullptr
     int B, H, W, Cin, Cin2, Cout;
@@ -38,45 +42,101 @@ struct ConvArgs {
     int act;             // 0 none, 1 GELU, 2 multiply by GELU'(aux)
 };
 
-template <int MT>
+// geometry for NT 16-pixel tiles per wave (4 waves along N, tile width 32)
+template <int NT>
+struct ConvGeom {
+    static constexpr int TW = 32;
+    static constexpr int TPR = TW / 16;
+    static constexpr int RPW = NT / TPR;                 // tile rows per wave
+    static constexpr int TH = 4 * RPW;                   // tile height
+    static constexpr int RS = TW + 2;
+    static constexpr int HR = TH + 2;
+    static constexpr int PS = ((HR * RS - 16 + 31) / 32) * 32 + 16;   // plane stride == 16 mod 32
+    static constexpr int IN_ELEMS = KC * HR * RS;
+    static constexpr int IREGS = (IN_ELEMS + CONV_THREADS - 1) / CONV_THREADS;
+};
+
+template <int MT, int NT>
 struct ConvCfg {
+    using G = ConvGeom<NT>;
     static constexpr int CO_LDS = (MT * 16) % 32 == 16 ? MT * 16 : MT * 16 + 16;
     static constexpr int W3_F4 = 9 * KC * CO_LDS / 4;   // float4 per 3x3 chunk
     static constexpr int W1_F4 = KC * CO_LDS / 4;       // float4 per 1x1 chunk
     static constexpr int WREGS = (W3_F4 + CONV_THREADS - 1) / CONV_THREADS;
-    static constexpr int LDS_FLOATS = 9 * KC * CO_LDS + KC * CONV_PS;
+    static constexpr int LDS_FLOATS = 9 * KC * CO_LDS + KC * G::PS;
 };
 
-template <int MT, int TAPS>
-__device__ __forceinline__ void conv_compute_chunk(f32x4 (&acc)[MT][CONV_NT], const float* __restrict__ sW,
+template <int MT, int NT>
+struct Frag {
+    float a[MT];
+    float b[NT];
+};
+
+template <int MT, int NT, int TAPS>
+__device__ __forceinline__ void conv_load_frag(Frag<MT, NT>& f, const float* __restrict__ sW,
+                                               const float* __restrict__ sIn, int aBase, int bBase, int step) {
+    using G = ConvGeom<NT>;
+    constexpr int CO_LDS = ConvCfg<MT, NT>::CO_LDS;
+    const int tap = step / (KC / 4), ks = step % (KC / 4);
+    const int dy = (TAPS == 9) ? tap / 3 : 1;
+    const int dx = (TAPS == 9) ? tap % 3 : 1;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = sW[aBase + (tap * KC + ks * 4) * CO_LDS + mt * 16];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+        f.b[nt] = sIn[bBase + ks * 4 * G::PS + ((nt / G::TPR) + dy) * G::RS + (nt % G::TPR) * 16 + dx];
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_mfma_frag(f32x4 (&acc)[MT][NT], const Frag<MT, NT>& f) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt], f.b[nt], acc[mt][nt], 0, 0, 0);
+}
+
+// VAR 0: let the compiler schedule LDS reads.  VAR 1: explicit register double buffering of the
+// fragments, pinned with sched_barrier so that the reads of step i+1 are issued before the MFMAs of
+// step i.
+template <int MT, int NT, int TAPS, int VAR>
+__device__ __forceinline__ void conv_compute_chunk(f32x4 (&acc)[MT][NT], const float* __restrict__ sW,
                                                    const float* __restrict__ sIn, int aBase, int bBase) {
-    constexpr int CO_LDS = ConvCfg<MT>::CO_LDS;
+    constexpr int NSTEP = TAPS * (KC / 4);
+    if constexpr (VAR == 0) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-        const int dy = (TAPS == 9) ? tap / 3 : 1;
-        const int dx = (TAPS == 9) ? tap % 3 : 1;
+        for (int st = 0; st < NSTEP; ++st) {
+            Frag<MT, NT> f;
+            conv_load_frag<MT, NT, TAPS>(f, sW, sIn, aBase, bBase, st);
+            conv_mfma_frag<MT, NT>(acc, f);
+        }
+    } else {
+        Frag<MT, NT> f0, f1;
+        conv_load_frag<MT, NT, TAPS>(f0, sW, sIn, aBase, bBase, 0);
 #pragma unroll
-        for (int ks = 0; ks < KC / 4; ++ks) {
-            float a[MT], b[CONV_NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = sW[aBase + (tap * KC + ks * 4) * CO_LDS + mt * 16];
-#pragma unroll
-            for (int nt = 0; nt < CONV_NT; ++nt)
-                b[nt] = sIn[bBase + ks * 4 * CONV_PS + ((nt / CONV_TPR) + dy) * CONV_RS + (nt % CONV_TPR) * 16 + dx];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < CONV_NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        for (int st = 0; st < NSTEP; st += 2) {
+            if (st + 1 < NSTEP) conv_load_frag<MT, NT, TAPS>(f1, sW, sIn, aBase, bBase, st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            conv_mfma_frag<MT, NT>(acc, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < NSTEP) {
+                if (st + 2 < NSTEP) conv_load_frag<MT, NT, TAPS>(f0, sW, sIn, aBase, bBase, st + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                conv_mfma_frag<MT, NT>(acc, f1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
 
-template <int MT>
+template <int MT, int NT, int VAR>
 __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
-    using Cfg = ConvCfg<MT>;
+    using Cfg = ConvCfg<MT, NT>;
+    using G = ConvGeom<NT>;
     constexpr int CO_LDS = Cfg::CO_LDS;
     constexpr int WREGS = Cfg::WREGS;
+    constexpr int IREGS = G::IREGS;
+    constexpr int PLANE = G::HR * G::RS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sW = smem;
     float* sIn = smem + 9 * KC * CO_LDS;
@@ -88,7 +148,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
     const int slot = id >> 3;
     const int cb = slot % p.coblks;
     const int tl = slot / p.coblks;
-    if (tl >= p.tiles_per_xcd) return;
     const int tile = xcd * p.tiles_per_xcd + tl;
     if (tile >= p.ntiles) return;
     const int tpi = p.tilesX * p.tilesY;
@@ -96,7 +155,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
     const int tr = tile - b * tpi;
     const int ty = tr / p.tilesX;
     const int tx = tr - ty * p.tilesX;
-    const int y0 = ty * CONV_TH, x0 = tx * CONV_TW;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,21 +165,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
     const int HW = H * W;
 
     // ---- per-thread staging map (same for every chunk) ----
-    int goff[CONV_IREGS];
+    int goff[IREGS];
 #pragma unroll
-    for (int i = 0; i < CONV_IREGS; ++i) {
+    for (int i = 0; i < IREGS; ++i) {
         const int idx = tid + i * CONV_THREADS;
-        const int kc = idx / (CONV_HR * CONV_RS);
-        const int e = idx - kc * (CONV_HR * CONV_RS);
-        const int r = e / CONV_RS;
-        const int c = e - r * CONV_RS;
+        const int kc = idx / PLANE;
+        const int e = idx - kc * PLANE;
+        const int r = e / G::RS;
+        const int c = e - r * G::RS;
         const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = idx < CONV_IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool ok = idx < G::IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         goff[i] = ok ? kc * HW + gy * W + gx : -1;
     }
 
     float4 wreg[WREGS];
-    float ireg[CONV_IREGS];
+    float ireg[IREGS];
 
     const int nch = p.nch3 + p.nch1;
     auto load_chunk = [&](int c) {
@@ -132,9 +191,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
         const float* sbase = src + ((size_t)b * C + ch0) * HW;
         const int nvalid = C - ch0;  // channels of this chunk that exist
 #pragma unroll
-        for (int i = 0; i < CONV_IREGS; ++i) {
+        for (int i = 0; i < IREGS; ++i) {
             const int idx = tid + i * CONV_THREADS;
-            const int kc = idx / (CONV_HR * CONV_RS);
+            const int kc = idx / PLANE;
             ireg[i] = (goff[i] >= 0 && kc < nvalid) ? sbase[goff[i]] : 0.0f;
         }
         const float4* wsrc;
@@ -160,35 +219,43 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
             if (i4 < n4) reinterpret_cast<float4*>(sW)[i4] = wreg[j];
         }
 #pragma unroll
-        for (int i = 0; i < CONV_IREGS; ++i) {
+        for (int i = 0; i < IREGS; ++i) {
             const int idx = tid + i * CONV_THREADS;
-            if (idx < CONV_IN_ELEMS) {
-                const int kc = idx / (CONV_HR * CONV_RS);
-                const int e = idx - kc * (CONV_HR * CONV_RS);
-                sIn[kc * CONV_PS + e] = ireg[i];
+            if (idx < G::IN_ELEMS) {
+                const int kc = idx / PLANE;
+                const int e = idx - kc * PLANE;
+                sIn[kc * G::PS + e] = ireg[i];
             }
         }
     };
 
-    f32x4 acc[MT][CONV_NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < CONV_NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int aBase = kq * CO_LDS + l16;
-    const int bBase = kq * CONV_PS + (wave * (CONV_NT / CONV_TPR)) * CONV_RS + l16;
+    const int bBase = kq * G::PS + (wave * G::RPW) * G::RS + l16;
 
+    // VAR 2 / 3 are timing ablations only (wrong results): 2 = MFMA loop without the per-chunk
+    // staging, 3 = staging without the MFMA loop.
     load_chunk(0);
     for (int c = 0; c < nch; ++c) {
-        __syncthreads();            // every wave finished reading the previous chunk
-        store_chunk(c);
-        __syncthreads();
-        if (c + 1 < nch) load_chunk(c + 1);   // in flight during the MFMAs below
+        if (VAR != 2 || c == 0) {
+            __syncthreads();            // every wave finished reading the previous chunk
+            store_chunk(c);
+            __syncthreads();
+            if (c + 1 < nch) load_chunk(c + 1);   // in flight during the MFMAs below
+        }
+        if (VAR == 3) {
+            acc[0][0][0] += sW[aBase] * sIn[bBase];
+            continue;
+        }
         if (c < p.nch3)
-            conv_compute_chunk<MT, 9>(acc, sW, sIn, aBase, bBase);
+            conv_compute_chunk<MT, NT, 9, (VAR == 1 ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
         else
-            conv_compute_chunk<MT, 1>(acc, sW, sIn, aBase, bBase);
+            conv_compute_chunk<MT, NT, 1, (VAR == 1 ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
     }
 
     // ---- epilogue: bias, activation, residual, store (C/D layout: col = lane&15 -> pixel,
@@ -203,9 +270,152 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
             const float bv = p.bias ? p.bias[cb * (MT * 16) + col] : 0.0f;
             const size_t cbase = ((size_t)b * p.Cout + co) * HW;
 #pragma unroll
-            for (int nt = 0; nt < CONV_NT; ++nt) {
-                const int y = y0 + wave * (CONV_NT / CONV_TPR) + nt / CONV_TPR;
-                const int x = x0 + (nt % CONV_TPR) * 16 + l16;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int y = y0 + wave * G::RPW + nt / G::TPR;
+                const int x = x0 + (nt % G::TPR) * 16 + l16;
+                if (y < H && x < W) {
+                    const size_t o = cbase + (size_t)y * W + x;
+                    float v = acc[mt][nt][r] + bv;
+                    if (p.out_pre) p.out_pre[o] = v;
+                    if (p.act == 1) v = gelu_erf(v);
+                    else if (p.act == 2) v *= gelu_erf_grad(p.aux[o]);
+                    if (p.resid) v += p.resid[o];
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// LDS-DMA variant: both operands go global -> LDS with global_load_lds (no VGPR round trip, no
+// ds_write pass), LDS is double buffered and there is ONE barrier per K chunk:
+//     issue DMA(chunk c+1 -> buf[(c+1)&1]) ; MFMAs(chunk c from buf[c&1]) ; vmcnt(0) ; barrier
+// The DMA destination is lane-linear (wave-uniform base + lane*size), so the LDS images are walked
+// linearly (including the pad floats of every plane); halo / out-of-image / missing-channel
+// elements are fetched from a page of zeros instead of being predicated off.
+// =====================================================================================
+template <int MT, int NT, int PIN>
+__global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p) {
+    using Cfg = ConvCfg<MT, NT>;
+    using G = ConvGeom<NT>;
+    constexpr int CO_LDS = Cfg::CO_LDS;
+    constexpr int WREGS = Cfg::WREGS;
+    constexpr int PLANE = G::HR * G::RS;
+    constexpr int IN_LIN = KC * G::PS;                                   // multiple of 64
+    constexpr int IREGS = (IN_LIN + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int BUF = Cfg::LDS_FLOATS;                                 // floats per buffer
+    static_assert(IN_LIN % 64 == 0, "input image must be whole wave-instructions");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int cb = slot % p.coblks;
+    const int tl = slot / p.coblks;
+    const int tile = xcd * p.tiles_per_xcd + tl;
+    if (tile >= p.ntiles) return;
+    const int tpi = p.tilesX * p.tilesY;
+    const int b = tile / tpi;
+    const int tr = tile - b * tpi;
+    const int ty = tr / p.tilesX;
+    const int tx = tr - ty * p.tilesX;
+    const int y0 = ty * G::TH, x0 = tx * G::TW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+
+    // per-thread source map of the input image (same for every chunk): element idx of the linear LDS
+    // image [kc][PS] -> offset inside the chunk's 8 channel planes, or -1 (zero fill)
+    int goff[IREGS];
+#pragma unroll
+    for (int i = 0; i < IREGS; ++i) {
+        const int idx = tid + i * CONV_THREADS;
+        const int kc = idx / G::PS;
+        const int e = idx - kc * G::PS;
+        const int r = e / G::RS;
+        const int c = e - r * G::RS;
+        const int gy = y0 + r - 1, gx = x0 + c - 1;
+        const bool ok = idx < IN_LIN && e < PLANE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[i] = ok ? kc * HW + gy * W + gx : -1;
+    }
+    const float* zsrc = p.zero + lane;
+
+    const int nch = p.nch3 + p.nch1;
+    auto issue = [&](int c, float* buf) {
+        const bool is3 = c < p.nch3;
+        const int cc = is3 ? c : c - p.nch3;
+        const float* src = is3 ? p.in : p.in2;
+        const int C = is3 ? p.Cin : p.Cin2;
+        const int ch0 = cc * KC;
+        const float* sbase = src + ((size_t)b * C + ch0) * HW;
+        const int nvalid = C - ch0;
+        const float4* wsrc;
+        int n4;
+        if (is3) {
+            wsrc = reinterpret_cast<const float4*>(p.w3) + ((size_t)cb * p.nch3 + cc) * Cfg::W3_F4;
+            n4 = Cfg::W3_F4;
+        } else {
+            wsrc = reinterpret_cast<const float4*>(p.w1) + ((size_t)cb * p.nch1 + cc) * Cfg::W1_F4;
+            n4 = Cfg::W1_F4;
+        }
+#pragma unroll
+        for (int j = 0; j < WREGS; ++j) {
+            const int i4 = tid + j * CONV_THREADS;
+            if (i4 < n4)
+                __builtin_amdgcn_global_load_lds(wsrc + i4, (lds_ptr)(buf + (j * CONV_THREADS + wave * 64) * 4), 16, 0, 0);
+        }
+        float* ibuf = buf + 9 * KC * CO_LDS;
+#pragma unroll
+        for (int i = 0; i < IREGS; ++i) {
+            const int idx = tid + i * CONV_THREADS;
+            if (idx < IN_LIN) {
+                const int kc = idx / G::PS;
+                const float* g = (goff[i] >= 0 && kc < nvalid) ? sbase + goff[i] : zsrc;
+                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ibuf + i * CONV_THREADS + wave * 64), 4, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int aBase = kq * CO_LDS + l16;
+    const int bBase = 9 * KC * CO_LDS + kq * G::PS + (wave * G::RPW) * G::RS + l16;
+
+    issue(0, smem);
+    __syncthreads();                       // (carries the vmcnt(0) of the pending DMA)
+    for (int c = 0; c < nch; ++c) {
+        float* cur = smem + (c & 1) * BUF;
+        if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
+        if (c < p.nch3)
+            conv_compute_chunk<MT, NT, 9, PIN>(acc, cur, cur, aBase, bBase);
+        else
+            conv_compute_chunk<MT, NT, 1, PIN>(acc, cur, cur, aBase, bBase);
+        __syncthreads();                   // everyone done with `cur`; DMA of chunk c+1 has landed
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = mt * 16 + kq * 4 + r;
+            const int co = cb * (MT * 16) + col;
+            if (co >= p.Cout) continue;
+            const float bv = p.bias ? p.bias[cb * (MT * 16) + col] : 0.0f;
+            const size_t cbase = ((size_t)b * p.Cout + co) * HW;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int y = y0 + wave * G::RPW + nt / G::TPR;
+                const int x = x0 + (nt % G::TPR) * 16 + l16;
                 if (y < H && x < W) {
                     const size_t o = cbase + (size_t)y * W + x;
                     float v = acc[mt][nt][r] + bv;
@@ -231,8 +441,60 @@ struct ConvProfiler {
 };
 ConvProfiler& conv_profiler();
 
+// tuning knobs (read once): SINDDM_CONV_NT in {2,4}, SINDDM_CONV_VAR in {0,1}
+struct ConvTuning {
+    int nt, var;
+};
+inline ConvTuning conv_tuning() {
+    static ConvTuning t = [] {
+        ConvTuning r{2, 0};
+        if (const char* e = getenv("SINDDM_CONV_NT")) r.nt = atoi(e) == 4 ? 4 : 2;
+        if (const char* e = getenv("SINDDM_CONV_VAR")) r.var = atoi(e) % 6;
+        return r;
+    }();
+    return t;
+}
+
+template <int MT, int NT, int VAR>
+inline void conv_launch_t(const ConvArgs& a, unsigned grid, hipStream_t st) {
+    constexpr size_t lds = ConvCfg<MT, NT>::LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, VAR>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+}
+
+template <int MT, int NT, int PIN>
+inline void conv_launch_dma_t(const ConvArgs& a, unsigned grid, hipStream_t st) {
+    constexpr size_t lds = 2 * ConvCfg<MT, NT>::LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_dma_kernel<MT, NT, PIN>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+}
+
+template <int MT>
+inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int nt, int var, hipStream_t st) {
+    if (var >= 4) {
+        if (nt == 4) { if (var == 5) conv_launch_dma_t<MT, 4, 1>(a, grid, st); else conv_launch_dma_t<MT, 4, 0>(a, grid, st); }
+        else         { if (var == 5) conv_launch_dma_t<MT, 2, 1>(a, grid, st); else conv_launch_dma_t<MT, 2, 0>(a, grid, st); }
+        return;
+    }
+    if (nt == 4) {
+        switch (var) {
+            case 1: conv_launch_t<MT, 4, 1>(a, grid, st); break;
+            case 2: conv_launch_t<MT, 4, 2>(a, grid, st); break;
+            case 3: conv_launch_t<MT, 4, 3>(a, grid, st); break;
+            default: conv_launch_t<MT, 4, 0>(a, grid, st);
+        }
+    } else {
+        switch (var) {
+            case 1: conv_launch_t<MT, 2, 1>(a, grid, st); break;
+            case 2: conv_launch_t<MT, 2, 2>(a, grid, st); break;
+            case 3: conv_launch_t<MT, 2, 3>(a, grid, st); break;
+            default: conv_launch_t<MT, 2, 0>(a, grid, st);
+        }
+    }
+}
+
 inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
+    const ConvTuning tune = conv_tuning();
+    const int TH = tune.nt == 4 ? ConvGeom<4>::TH : ConvGeom<2>::TH;
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
     if (rec) {
@@ -243,26 +505,16 @@ inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
         }
         (void)hipEventRecord(prof.ev[2 * prof.used], st);
     }
-    a.tilesX = (a.W + CONV_TW - 1) / CONV_TW;
-    a.tilesY = (a.H + CONV_TH - 1) / CONV_TH;
+    a.tilesX = (a.W + 31) / 32;
+    a.tilesY = (a.H + TH - 1) / TH;
     a.ntiles = a.B * a.tilesX * a.tilesY;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     const unsigned grid = (unsigned)(a.tiles_per_xcd * 8 * a.coblks);
     switch (mt) {
-        case 5:
-            hipLaunchKernelGGL(conv_mfma_kernel<5>, dim3(grid), dim3(CONV_THREADS),
-                               ConvCfg<5>::LDS_FLOATS * sizeof(float), st, a);
-            break;
-        case 2:
-            hipLaunchKernelGGL(conv_mfma_kernel<2>, dim3(grid), dim3(CONV_THREADS),
-                               ConvCfg<2>::LDS_FLOATS * sizeof(float), st, a);
-            break;
-        case 1:
-            hipLaunchKernelGGL(conv_mfma_kernel<1>, dim3(grid), dim3(CONV_THREADS),
-                               ConvCfg<1>::LDS_FLOATS * sizeof(float), st, a);
-            break;
-        default:
-            return SINDDM_E_BADSHAPE;
+        case 5: conv_launch_mt<5>(a, grid, tune.nt, tune.var, st); break;
+        case 2: conv_launch_mt<2>(a, grid, tune.nt, tune.var, st); break;
+        case 1: conv_launch_mt<1>(a, grid, tune.nt, tune.var, st); break;
+        default: return SINDDM_E_BADSHAPE;
     }
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);

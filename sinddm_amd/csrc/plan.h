@@ -31,6 +31,7 @@ struct NetPlan {
     BlockPlan blk[4];
     int64_t tm0_w, tm0_b, tm2_w, tm2_b, fin_w, fin_b;
     int64_t nparams, npacked;
+    int64_t pk_zero;   // 64 zero floats at the end of the packed image (LDS-DMA zero-fill source)
     int ntensors;
     int64_t tensor_off[64];
     int cond_stride;   // floats per sample of the cond-bias vector (sum of cin, padded to 4)
@@ -93,6 +94,8 @@ inline NetPlan make_plan(int dim) {
     p.fin_w = take((int64_t)CHANNELS * p.half);
     p.fin_b = take(CHANNELS);
     p.nparams = o;
+    p.pk_zero = q;
+    q += 64;
     p.npacked = q;
     p.ntensors = nt;
     p.cond_stride = (coff + 3) / 4 * 4;

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 // =====================================================================================
 struct BwdPack {
     // per block: dgrad of conv2 (cout->cout), dgrad of conv1 (cout->cin), dgrad of res 1x1 (cout->cin)
-    long long dg2[4], dg1[4], dres[4], dfin;
+    long long dg2[4], dg1[4], dres[4], dfin, zero;
     long long total;
     int mt2[4], mt1[4], cb2[4], cb1[4];
     int mtf, cbf;
@@ -439,6 +439,7 @@ static BwdPack make_bwd_pack(const NetPlan& P) {
     }
     k.mtf = mt_for(P.half); k.cbf = (P.half + k.mtf * 16 - 1) / (k.mtf * 16);
     k.dfin = q; q += (long long)k.cbf * 1 * KC * co_lds_for(k.mtf);     // K = 3 channels -> one chunk
+    k.zero = q; q += 64;
     k.total = q;
     return k;
 }
@@ -464,6 +465,12 @@ static int pack_backward(const NetPlan& P, const float* params, float* packed, h
         if (b.res_w >= 0) add(k.dres[l], b.res_w, b.cin, b.cout, 1, k.mt1[l], k.cb1[l]);
     }
     add(k.dfin, P.fin_w, P.half, CHANNELS, 1, k.mtf, k.cbf);
+    {
+        PackSeg z{};
+        z.kind = 2; z.dst = k.zero; z.count = 64;
+        a.seg[n++] = z;
+        total += z.count;
+    }
     a.nseg = n;
     a.total = total;
     // segments are laid out back to back in `packed` in the same order -> dst offsets are cumulative
@@ -502,10 +509,11 @@ static size_t carve_train(const NetPlan& P, int B, int H, int W, char* base, Tra
     return off;
 }
 
-static int conv1x1_or_3x3(const float* in3, int cin3, const float* w3, int nch3, const float* in1, int cin1,
-                          const float* w1, int nch1, const float* aux, int act, float* out, int Cout, int mt, int coblks,
-                          int B, int H, int W, hipStream_t st) {
+static int conv1x1_or_3x3(const float* zero, const float* in3, int cin3, const float* w3, int nch3, const float* in1,
+                          int cin1, const float* w1, int nch1, const float* aux, int act, float* out, int Cout, int mt,
+                          int coblks, int B, int H, int W, hipStream_t st) {
     ConvArgs c{};
+    c.zero = zero;
     c.in = in3; c.Cin = cin3; c.w3 = w3; c.nch3 = nch3;
     c.in2 = in1; c.Cin2 = cin1; c.w1 = w1; c.nch1 = nch1;
     c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
@@ -517,12 +525,13 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
                              const float* grad_out, float* grads, float* grad_x, int B, int H, int W,
                              const TrainBufs& tb, hipStream_t st) {
     const BwdPack k = make_bwd_pack(P);
+    const float* zp = packed_bwd + k.zero;
     int rc;
     // ---- final 1x1 conv: weight/bias grads, then data grad into s[0] ----
     rc = wgrad_launch(grad_out, tb.o[3], grads + P.fin_w, grads + P.fin_b, B, H, W, P.half, CHANNELS, 1, st);
     if (rc) return rc;
     int di = 0;   // index of the scratch buffer holding dOut of the current block
-    rc = conv1x1_or_3x3(nullptr, 0, nullptr, 0, grad_out, CHANNELS, packed_bwd + k.dfin, 1, nullptr, 0, tb.s[di],
+    rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, grad_out, CHANNELS, packed_bwd + k.dfin, 1, nullptr, 0, tb.s[di],
                         P.half, k.mtf, k.cbf, B, H, W, st);
     if (rc) return rc;
     for (int l = 3; l >= 0; --l) {
@@ -541,13 +550,13 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
             if (rc) return rc;
         }
         // dU = dgrad_conv2(dO) * GELU'(u)
-        rc = conv1x1_or_3x3(dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU, b.cout,
+        rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU, b.cout,
                             k.mt2[l], k.cb2[l], B, H, W, st);
         if (rc) return rc;
         // conv1 weight grads, dH = dgrad_conv1(dU)
         rc = wgrad_launch(dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
         if (rc) return rc;
-        rc = conv1x1_or_3x3(dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH, b.cin,
+        rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH, b.cin,
                             k.mt1[l], k.cb1[l], B, H, W, st);
         if (rc) return rc;
         // depthwise weight/bias grads and the per-sample condition grads
@@ -558,7 +567,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         if (l > 0 || grad_x) {
             const float* radd = dO;                      // identity residual
             if (b.res_w >= 0) {
-                rc = conv1x1_or_3x3(nullptr, 0, nullptr, 0, dO, b.cout, packed_bwd + k.dres[l], nchK, nullptr, 0, dU,
+                rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, dO, b.cout, packed_bwd + k.dres[l], nchK, nullptr, 0, dU,
                                     b.cin, k.mt1[l], k.cb1[l], B, H, W, st);     // dU is free again
                 if (rc) return rc;
                 radd = dU;

@@ -41,12 +41,12 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
             if (co_l < g.mt * 16 && m < g.cin && k < g.cout)
                 v = params[g.w + ((long long)k * g.cin + m) * g.taps + (g.taps - 1 - tap)];
         }
-    } else {
+    } else if (g.kind == 1) {
         if (j < g.cout) {
             v = params[g.w + j];
             if (g.w2 >= 0) v += params[g.w2 + j];
         }
-    }
+    }                       // kind 2: zero page
     packed[g.dst + j] = v;
 }
 
@@ -87,6 +87,9 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
         t.dst = b.pk_b2; t.w = b.c2_b; t.w2 = b.res_b;
         add(t);
     }
+    PackSeg z{};
+    z.kind = 2; z.dst = P.pk_zero; z.count = 64;
+    add(z);
     a.nseg = n;
     a.total = total;
     return pack_launch(params, packed, a, st);
@@ -401,7 +404,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         ConvArgs c1{};
         c1.in = hbuf; c1.w3 = packed + b.pk_c1; c1.bias = packed + b.pk_b1; c1.out = gbuf;
         c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch3 = b.nch1; c1.nch1 = 0;
-        c1.coblks = b.coblks; c1.act = 1;
+        c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
         rc = conv_launch(c1, b.mt, st);
         if (rc) return rc;
@@ -410,7 +413,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout; c2.nch3 = b.nch2;
         if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
         else { c2.resid = cur; c2.nch1 = 0; }
-        c2.coblks = b.coblks; c2.act = 0;
+        c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
         rc = conv_launch(c2, b.mt, st);
         if (rc) return rc;
         cur = obuf;
