@@ -393,14 +393,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p)
 
     issue(0, smem);
     __syncthreads();                       // (carries the vmcnt(0) of the pending DMA)
-    for (int c = 0; c < nch; ++c) {
+    int c = 0;
+    for (; c < p.nch3; ++c) {              // 3x3 chunks
         float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
-        if (c < p.nch3)
-            conv_compute_chunk<MT, NT, 9, PIN>(acc, cur, cur, aBase, bBase);
-        else
-            conv_compute_chunk<MT, NT, 1, PIN>(acc, cur, cur, aBase, bBase);
+        conv_compute_chunk<MT, NT, 9, PIN>(acc, cur, cur, aBase, bBase);
         __syncthreads();                   // everyone done with `cur`; DMA of chunk c+1 has landed
+    }
+    for (; c < nch; ++c) {                 // fused 1x1 (residual projection) chunks
+        float* cur = smem + (c & 1) * BUF;
+        if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
+        conv_compute_chunk<MT, NT, 1, PIN>(acc, cur, cur, aBase, bBase);
+        __syncthreads();
     }
 
 #pragma unroll
@@ -447,8 +451,8 @@ struct ConvTuning {
 };
 inline ConvTuning conv_tuning() {
     static ConvTuning t = [] {
-        ConvTuning r{2, 0};
-        if (const char* e = getenv("SINDDM_CONV_NT")) r.nt = atoi(e) == 4 ? 4 : 2;
+        ConvTuning r{0, 4};   // nt 0 = pick per launch
+        if (const char* e = getenv("SINDDM_CONV_NT")) r.nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 0);
         if (const char* e = getenv("SINDDM_CONV_VAR")) r.var = atoi(e) % 6;
         return r;
     }();
@@ -493,7 +497,13 @@ inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int nt, int var, hi
 
 inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
-    const ConvTuning tune = conv_tuning();
+    ConvTuning tune = conv_tuning();
+    if (tune.nt == 0) {
+        // 8x32 tiles amortise the weight staging best; fall back to 4x32 tiles when they would not give
+        // every CU at least two rounds of workgroups (small pyramid scales / small batches)
+        const long long blocks8 = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.coblks;
+        tune.nt = blocks8 >= 1024 ? 4 : 2;
+    }
     const int TH = tune.nt == 4 ? ConvGeom<4>::TH : ConvGeom<2>::TH;
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
