@@ -203,14 +203,14 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
                                                             float* __restrict__ gw, float* __restrict__ gb,
                                                             float* __restrict__ dcond, int cond_stride, int C, int H,
                                                             int W) {
-    __shared__ __attribute__((aligned(16))) float tile[DWB_HR * DWB_RS];
+    __shared__ float tile[DWB_HR * DWB_RS];
     __shared__ float red[4][26];
     const int c = blockIdx.x, b = blockIdx.y;
     const size_t plane = ((size_t)b * C + c) * H * W;
     const float* xs = x + plane;
     const float* ds = dh + plane;
     const int tilesX = (W + DWB_TW - 1) / DWB_TW, tilesY = (H + DWB_TH - 1) / DWB_TH;
-    const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;    // wave wv: tile rows 4wv..4wv+3, lane: column
     float acc[26];
 #pragma unroll
     for (int k = 0; k < 26; ++k) acc[k] = 0.f;
@@ -224,22 +224,26 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
             tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xs[(size_t)gy * W + gx] : 0.0f;
         }
         __syncthreads();
-        const int gy = y0 + r, gx = x0 + xg * 4;
+        const int gx = x0 + ln;
         float d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = (gy < H && gx + i < W) ? ds[(size_t)gy * W + gx + i] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int gy = y0 + wv * 4 + i;
+            d[i] = (gy < H && gx < W) ? ds[(size_t)gy * W + gx] : 0.f;
+        }
         acc[25] += (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-            const float4 lo = *reinterpret_cast<const float4*>(&tile[(r + dy) * DWB_RS + xg * 4]);
-            const float4 hi = *reinterpret_cast<const float4*>(&tile[(r + dy) * DWB_RS + xg * 4 + 4]);
-            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        for (int dy = 0; dy < 8; ++dy) {
+            float v[5];
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
-                float sacc = acc[dy * 5 + dx];
+            for (int dx = 0; dx < 5; ++dx) v[dx] = tile[(wv * 4 + dy) * DWB_RS + ln + dx];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sacc = fmaf(d[i], v[dx + i], sacc);
-                acc[dy * 5 + dx] = sacc;
+            for (int i = 0; i < 4; ++i) {
+                const int ky = dy - i;
+                if (ky >= 0 && ky < 5) {
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx) acc[ky * 5 + dx] = fmaf(d[i], v[dx], acc[ky * 5 + dx]);
+                }
             }
         }
     }

@@ -180,8 +180,10 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
 
 // =====================================================================================
 // depthwise 5x5 + bias + per-sample condition      reference SinDDM/models.py:61,70,77
-// HBM-bound: 8 B per (channel,pixel).  Tile 16x64 staged with its 2-pixel halo in LDS,
-// each thread produces a 1x4 output strip from 5 rows x 8 floats (two b128 reads per row).
+// HBM-bound: 8 B per (channel,pixel).  A 16x64 tile is staged with its 2-pixel halo in LDS; wave w owns
+// tile rows 4w..4w+3 and lane l owns column l, so every global store (and every LDS read) of a wave is
+// 64 consecutive floats.  With flip=1 the taps are mirrored (transposed conv = data gradient) and
+// `addt` is added to the result (residual-path gradient).
 // =====================================================================================
 constexpr int DW_TH = 16, DW_TW = 64, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
 
@@ -189,11 +191,12 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
                                                        int cond_stride, const float* __restrict__ addt, int flip,
                                                        float* __restrict__ out, int C, int H, int W, int tilesX) {
-    __shared__ __attribute__((aligned(16))) float tile[DW_HR * DW_RS];
+    __shared__ float tile[DW_HR * DW_RS];
     const int c = blockIdx.y, b = blockIdx.z;
     const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
     const int y0 = ty * DW_TH, x0 = tx * DW_TW;
-    const float* src = x + ((size_t)b * C + c) * H * W;
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* src = x + plane;
     for (int i = threadIdx.x; i < DW_HR * DW_RS; i += 256) {
         const int r = i / DW_RS, cc = i - r * DW_RS;
         const int gy = y0 + r - 2, gx = x0 + cc - 2;
@@ -204,38 +207,32 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + (flip ? 24 - k : k)];   // flip -> transposed conv (data grad)
     const float add = (bias ? bias[c] : 0.0f) + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
     __syncthreads();
-    const int r = threadIdx.x >> 4, xg = threadIdx.x & 15;
-    float o0 = add, o1 = add, o2 = add, o3 = add;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float o[4] = {add, add, add, add};
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy) {
-        const float4 lo = *reinterpret_cast<const float4*>(&tile[(r + dy) * DW_RS + xg * 4]);
-        const float4 hi = *reinterpret_cast<const float4*>(&tile[(r + dy) * DW_RS + xg * 4 + 4]);
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int dy = 0; dy < 8; ++dy) {
+        float v[5];
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) {
-            const float wv = wk[dy * 5 + dx];
-            o0 = fmaf(wv, v[dx], o0);
-            o1 = fmaf(wv, v[dx + 1], o1);
-            o2 = fmaf(wv, v[dx + 2], o2);
-            o3 = fmaf(wv, v[dx + 3], o3);
+        for (int dx = 0; dx < 5; ++dx) v[dx] = tile[(wv * 4 + dy) * DW_RS + lane + dx];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ky = dy - r;
+            if (ky >= 0 && ky < 5) {
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) o[r] = fmaf(wk[ky * 5 + dx], v[dx], o[r]);
+            }
         }
     }
-    const int gy = y0 + r;
-    if (gy < H) {
-        const size_t rowo = (((size_t)b * C + c) * H + gy) * W;
-        float* dst = out + rowo;
-        const int gx = x0 + xg * 4;
-        if (addt) {
-            const float* as = addt + rowo;
-            if (gx < W) o0 += as[gx];
-            if (gx + 1 < W) o1 += as[gx + 1];
-            if (gx + 2 < W) o2 += as[gx + 2];
-            if (gx + 3 < W) o3 += as[gx + 3];
+    const int gx = x0 + lane;
+    if (gx < W) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gy = y0 + wv * 4 + r;
+            if (gy < H) {
+                const size_t oidx = plane + (size_t)gy * W + gx;
+                out[oidx] = addt ? o[r] + addt[oidx] : o[r];
+            }
         }
-        if (gx < W) dst[gx] = o0;
-        if (gx + 1 < W) dst[gx + 1] = o1;
-        if (gx + 2 < W) dst[gx + 2] = o2;
-        if (gx + 3 < W) dst[gx + 3] = o3;
     }
 }
 
