@@ -13,22 +13,26 @@ namespace sinddm {
 //   gw[co][ci][tap] += sum_{b,y,x} dout[b][co][y][x] * in[b][ci][y+dy-1][x+dx-1]
 // GEMM view: M = co (16-row tiles), N = ci (one 16-col tile per tap), K = pixels (4 per MFMA).
 // A workgroup owns one (co-block of MT*16, ci-block of 16) slab of the gradient and walks a strided
-// subset of the 4x32 pixel tiles; its 4 waves split the tile's rows (K split), each holding all
-// MT x TAPS accumulator tiles in registers across the whole walk.  At the end the 4 partial slabs are
-// combined in LDS and added to the global gradient with one atomic per element.
+// subset of the 2x32 pixel tiles; its 4 waves split the tile's 16 k-steps (K split), each holding all
+// MT x TAPS accumulator tiles (180 registers at MT=5, TAPS=9) across the whole walk.  Both operand
+// tiles are fetched with LDS DMA (global_load_lds: one wave instruction per dout channel row / per
+// input (channel,row); out-of-image and missing-channel rows come from a page of zeros) into a
+// double-buffered LDS image, ONE barrier per tile.  At the end the 4 partial slabs are combined in
+// LDS and added to the global gradient with one atomic per element.
 // LDS strides == 2 (mod 32) make both operand reads (lane -> channel*stride + pixel) conflict-free.
 // =====================================================================================
 constexpr int WG_THREADS = 256;
-constexpr int WG_TH = 4, WG_TW = 32;
+constexpr int WG_TH = 2, WG_TW = 32;
 constexpr int WG_CI = 16;
-constexpr int WG_PSO = WG_TH * WG_TW + 2;              // 130
+constexpr int WG_PSO = WG_TH * WG_TW + 2;              // 66
 constexpr int WG_IRS = WG_TW + 2;                      // 34
-constexpr int WG_IHR = WG_TH + 2;                      // 6
-constexpr int WG_PSI = ((WG_IHR * WG_IRS - 2 + 31) / 32) * 32 + 2;   // 226
+constexpr int WG_IHR = WG_TH + 2;                      // 4
+constexpr int WG_PSI = ((WG_IHR * WG_IRS - 2 + 31) / 32) * 32 + 2;   // 162
 
 struct WgradArgs {
     const float* dout;   // [B][Cout][H][W]
     const float* in;     // [B][Cin][H][W]
+    const float* zero;   // >= 64 zero floats
     float* gw;           // [Cout][Cin][TAPS]   (+=)
     float* gb;           // [Cout] (+=) or nullptr
     int B, H, W, Cin, Cout;
@@ -38,9 +42,9 @@ struct WgradArgs {
 
 template <int MT, int TAPS>
 __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sO = smem;                       // [MT*16][WG_PSO]
-    float* sI = smem + MT * 16 * WG_PSO;    // [16][WG_PSI]
+    constexpr int BUF = MT * 16 * WG_PSO + WG_CI * WG_PSI;   // floats per buffer
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -50,10 +54,50 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
     const int s = (slot / pairs) * 8 + xcd;          // pixel-split index; same-split slabs share an XCD/L2
     const int cb = q / p.ciblks, cib = q - cb * p.ciblks;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, kq = lane >> 4;
     const int H = p.H, W = p.W, HW = H * W;
     const int tpi = p.tilesX * p.tilesY;
+    const float* zsrc = p.zero + lane;
+
+    auto issue = [&](int tile, float* buf) {
+        const int b = tile / tpi;
+        const int tr = tile - b * tpi;
+        const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+        const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+        // dout tile: one wave instruction per channel row of 64 pixels (lane -> (row, col))
+        {
+            const int r = lane >> 5, c = lane & 31;
+            const bool ok = (y0 + r < H) && (x0 + c < W);
+            const int off = (y0 + r) * W + x0 + c;
+            const float* base = p.dout + (size_t)b * p.Cout * HW;
+#pragma unroll 4
+            for (int k = 0; k < MT * 4; ++k) {
+                const int col = wave + 4 * k;
+                const int co = cb * MT * 16 + col;
+                const float* g = (ok && co < p.Cout) ? base + (size_t)co * HW + off : zsrc;
+                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(buf + col * WG_PSO), 4, 0, 0);
+            }
+        }
+        // input tile with 1-pixel halo: one wave instruction per (channel, row), 34 active lanes
+        if (lane < WG_IRS) {
+            const int gx = x0 + lane - 1;
+            const bool okx = gx >= 0 && gx < W;
+            const float* base = p.in + (size_t)b * p.Cin * HW;
+            float* ibuf = buf + MT * 16 * WG_PSO;
+#pragma unroll 4
+            for (int k = 0; k < WG_CI * WG_IHR / 4; ++k) {
+                const int qi = wave + 4 * k;
+                const int cil = qi / WG_IHR, r = qi - cil * WG_IHR;
+                const int ci = cib * WG_CI + cil;
+                const int gy = y0 + r - 1;
+                const bool ok = okx && ci < p.Cin && gy >= 0 && gy < H;
+                const float* g = ok ? base + (size_t)ci * HW + (size_t)gy * W + gx : zsrc;
+                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ibuf + cil * WG_PSI + r * WG_IRS), 4, 0, 0);
+            }
+        }
+    };
 
     f32x4 acc[MT][TAPS];
 #pragma unroll
@@ -64,52 +108,30 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bsum[mt] = 0.f;
 
-    for (int tile = s; tile < p.ntiles; tile += p.S) {
-        const int b = tile / tpi;
-        const int tr = tile - b * tpi;
-        const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
-        const int y0 = ty * WG_TH, x0 = tx * WG_TW;
-        __syncthreads();
-        // dout tile: MT*16 channels x (4 x 32) pixels, zero outside the image / channel range
-        for (int idx = tid; idx < MT * 16 * WG_TH * WG_TW; idx += WG_THREADS) {
-            const int col = idx / (WG_TH * WG_TW);
-            const int e = idx - col * (WG_TH * WG_TW);
-            const int r = e / WG_TW, c = e - r * WG_TW;
-            const int co = cb * MT * 16 + col;
-            const int gy = y0 + r, gx = x0 + c;
-            float v = 0.f;
-            if (co < p.Cout && gy < H && gx < W) v = p.dout[((size_t)b * p.Cout + co) * HW + (size_t)gy * W + gx];
-            sO[col * WG_PSO + e] = v;
-        }
-        // input tile with 1-pixel halo: 16 channels x (6 x 34)
-        for (int idx = tid; idx < WG_CI * WG_IHR * WG_IRS; idx += WG_THREADS) {
-            const int cil = idx / (WG_IHR * WG_IRS);
-            const int e = idx - cil * (WG_IHR * WG_IRS);
-            const int r = e / WG_IRS, c = e - r * WG_IRS;
-            const int ci = cib * WG_CI + cil;
-            const int gy = y0 + r - 1, gx = x0 + c - 1;
-            float v = 0.f;
-            if (ci < p.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = p.in[((size_t)b * p.Cin + ci) * HW + (size_t)gy * W + gx];
-            sI[cil * WG_PSI + e] = v;
-        }
-        __syncthreads();
-        // wave `wave` owns tile row `wave`: 8 k-steps of 4 consecutive pixels
-        const int aBase = l16 * WG_PSO + wave * WG_TW + kq;
-        const int bBase = l16 * WG_PSI + wave * WG_IRS + kq;
+    // wave -> (tile row, half row): 4 k-steps of 4 consecutive pixels each
+    const int wr = wave >> 1, wh = wave & 1;
+    const int aBase = l16 * WG_PSO + wr * WG_TW + wh * 16 + kq;
+    const int bBase = MT * 16 * WG_PSO + l16 * WG_PSI + wr * WG_IRS + wh * 16 + kq;
+
+    int it = 0;
+    if (s < p.ntiles) issue(s, smem);
+    for (int tile = s; tile < p.ntiles; tile += p.S, ++it) {
+        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+        float* cur = smem + (it & 1) * BUF;
+        if (tile + p.S < p.ntiles) issue(tile + p.S, smem + ((it + 1) & 1) * BUF);
 #pragma unroll 1
-        for (int j = 0; j < WG_TW / 4; ++j) {
+        for (int j = 0; j < 4; ++j) {
             float a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                a[mt] = sO[aBase + mt * 16 * WG_PSO + 4 * j];
+                a[mt] = cur[aBase + mt * 16 * WG_PSO + 4 * j];
                 bsum[mt] += a[mt];
             }
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int dy = (TAPS == 9) ? t / 3 : 1;
                 const int dx = (TAPS == 9) ? t % 3 : 1;
-                const float bv = sI[bBase + dy * WG_IRS + 4 * j + dx];
+                const float bv = cur[bBase + dy * WG_IRS + 4 * j + dx];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt][t], 0, 0, 0);
@@ -120,7 +142,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
     // ---- combine the 4 waves' partial slabs in LDS, then one global atomic per element ----
     __syncthreads();
     constexpr int SLAB = MT * 16 * WG_CI * TAPS;
-    float* sR = smem;            // SLAB floats (fits: SLAB <= MT*16*WG_PSO + 16*WG_PSI for TAPS <= 9)
+    static_assert(SLAB + MT * 16 <= 2 * BUF, "reduction slab must fit in the staging buffers");
+    float* sR = smem;            // SLAB floats
     float* sB = smem + SLAB;     // MT*16 floats
     for (int i = tid; i < SLAB + MT * 16; i += WG_THREADS) sR[i] = 0.f;
     __syncthreads();
@@ -158,13 +181,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
 
 template <int MT, int TAPS>
 static void wgrad_launch_t(const WgradArgs& a, unsigned grid, hipStream_t st) {
-    constexpr size_t lds = (size_t)(MT * 16 * WG_PSO + WG_CI * WG_PSI) * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (MT * 16 * WG_PSO + WG_CI * WG_PSI) * sizeof(float);
     hipLaunchKernelGGL((wgrad_mfma_kernel<MT, TAPS>), dim3(grid), dim3(WG_THREADS), lds, st, a);
 }
 
-static int wgrad_launch(const float* dout, const float* in, float* gw, float* gb, int B, int H, int W, int Cin,
-                        int Cout, int taps, hipStream_t st) {
+static int wgrad_launch(const float* zero, const float* dout, const float* in, float* gw, float* gb, int B, int H, int W,
+                        int Cin, int Cout, int taps, hipStream_t st) {
     WgradArgs a{};
+    a.zero = zero;
     a.dout = dout; a.in = in; a.gw = gw; a.gb = gb;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const int mt = mt_for(Cout);
@@ -532,7 +556,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
     const float* zp = packed_bwd + k.zero;
     int rc;
     // ---- final 1x1 conv: weight/bias grads, then data grad into s[0] ----
-    rc = wgrad_launch(grad_out, tb.o[3], grads + P.fin_w, grads + P.fin_b, B, H, W, P.half, CHANNELS, 1, st);
+    rc = wgrad_launch(zp, grad_out, tb.o[3], grads + P.fin_w, grads + P.fin_b, B, H, W, P.half, CHANNELS, 1, st);
     if (rc) return rc;
     int di = 0;   // index of the scratch buffer holding dOut of the current block
     rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, grad_out, CHANNELS, packed_bwd + k.dfin, 1, nullptr, 0, tb.s[di],
@@ -547,10 +571,10 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         float* dX = tb.s[(di + 3) & 3];
         const int nchK = (b.cout + KC - 1) / KC;
         // conv2 + residual projection weight grads
-        rc = wgrad_launch(dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st);
+        rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st);
         if (rc) return rc;
         if (b.res_w >= 0) {
-            rc = wgrad_launch(dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
+            rc = wgrad_launch(zp, dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
             if (rc) return rc;
         }
         // dU = dgrad_conv2(dO) * GELU'(u)
@@ -558,7 +582,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
                             k.mt2[l], k.cb2[l], B, H, W, st);
         if (rc) return rc;
         // conv1 weight grads, dH = dgrad_conv1(dU)
-        rc = wgrad_launch(dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
+        rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
         if (rc) return rc;
         rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH, b.cin,
                             k.mt1[l], k.cb1[l], B, H, W, st);
