@@ -43,12 +43,12 @@ struct ConvArgs {
 };
 
 // geometry for NT 16-pixel tiles per wave (4 waves along N, tile width 32)
-template <int NT>
+template <int NT, int WV = 4>
 struct ConvGeom {
     static constexpr int TW = 32;
     static constexpr int TPR = TW / 16;
     static constexpr int RPW = NT / TPR;                 // tile rows per wave
-    static constexpr int TH = 4 * RPW;                   // tile height
+    static constexpr int TH = WV * RPW;                  // tile height
     static constexpr int RS = TW + 2;
     static constexpr int HR = TH + 2;
     static constexpr int PS = ((HR * RS - 16 + 31) / 32) * 32 + 16;   // plane stride == 16 mod 32
@@ -56,9 +56,9 @@ struct ConvGeom {
     static constexpr int IREGS = (IN_ELEMS + CONV_THREADS - 1) / CONV_THREADS;
 };
 
-template <int MT, int NT>
+template <int MT, int NT, int WV = 4>
 struct ConvCfg {
-    using G = ConvGeom<NT>;
+    using G = ConvGeom<NT, WV>;
     static constexpr int CO_LDS = (MT * 16) % 32 == 16 ? MT * 16 : MT * 16 + 16;
     static constexpr int W3_F4 = 9 * KC * CO_LDS / 4;   // float4 per 3x3 chunk
     static constexpr int W1_F4 = KC * CO_LDS / 4;       // float4 per 1x1 chunk
@@ -72,11 +72,11 @@ struct Frag {
     float b[NT];
 };
 
-template <int MT, int NT, int TAPS>
+template <int MT, int NT, int TAPS, int WV = 4>
 __device__ __forceinline__ void conv_load_frag(Frag<MT, NT>& f, const float* __restrict__ sW,
                                                const float* __restrict__ sIn, int aBase, int bBase, int step) {
-    using G = ConvGeom<NT>;
-    constexpr int CO_LDS = ConvCfg<MT, NT>::CO_LDS;
+    using G = ConvGeom<NT, WV>;
+    constexpr int CO_LDS = ConvCfg<MT, NT, WV>::CO_LDS;
     const int tap = step / (KC / 4), ks = step % (KC / 4);
     const int dy = (TAPS == 9) ? tap / 3 : 1;
     const int dx = (TAPS == 9) ? tap % 3 : 1;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void conv_mfma_frag(f32x4 (&acc)[MT][NT], const Frag<
 // VAR 0: let the compiler schedule LDS reads.  VAR 1: explicit register double buffering of the
 // fragments, pinned with sched_barrier so that the reads of step i+1 are issued before the MFMAs of
 // step i.
-template <int MT, int NT, int TAPS, int VAR>
+template <int MT, int NT, int TAPS, int VAR, int WV = 4>
 __device__ __forceinline__ void conv_compute_chunk(f32x4 (&acc)[MT][NT], const float* __restrict__ sW,
                                                    const float* __restrict__ sIn, int aBase, int bBase) {
     constexpr int NSTEP = TAPS * (KC / 4);
@@ -107,20 +107,20 @@ __device__ __forceinline__ void conv_compute_chunk(f32x4 (&acc)[MT][NT], const f
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             Frag<MT, NT> f;
-            conv_load_frag<MT, NT, TAPS>(f, sW, sIn, aBase, bBase, st);
+            conv_load_frag<MT, NT, TAPS, WV>(f, sW, sIn, aBase, bBase, st);
             conv_mfma_frag<MT, NT>(acc, f);
         }
     } else {
         Frag<MT, NT> f0, f1;
-        conv_load_frag<MT, NT, TAPS>(f0, sW, sIn, aBase, bBase, 0);
+        conv_load_frag<MT, NT, TAPS, WV>(f0, sW, sIn, aBase, bBase, 0);
 #pragma unroll
         for (int st = 0; st < NSTEP; st += 2) {
-            if (st + 1 < NSTEP) conv_load_frag<MT, NT, TAPS>(f1, sW, sIn, aBase, bBase, st + 1);
+            if (st + 1 < NSTEP) conv_load_frag<MT, NT, TAPS, WV>(f1, sW, sIn, aBase, bBase, st + 1);
             __builtin_amdgcn_sched_barrier(0);
             conv_mfma_frag<MT, NT>(acc, f0);
             __builtin_amdgcn_sched_barrier(0);
             if (st + 1 < NSTEP) {
-                if (st + 2 < NSTEP) conv_load_frag<MT, NT, TAPS>(f0, sW, sIn, aBase, bBase, st + 2);
+                if (st + 2 < NSTEP) conv_load_frag<MT, NT, TAPS, WV>(f0, sW, sIn, aBase, bBase, st + 2);
                 __builtin_amdgcn_sched_barrier(0);
                 conv_mfma_frag<MT, NT>(acc, f1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
     // staging, 3 = staging without the MFMA loop.
     load_chunk(0);
     for (int c = 0; c < nch; ++c) {
-        if (VAR != 2 || c == 0) {
+        if ((VAR != 2 && VAR != 6 && VAR != 7) || c == 0) {
             __syncthreads();            // every wave finished reading the previous chunk
             store_chunk(c);
             __syncthreads();
@@ -252,10 +252,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
             acc[0][0][0] += sW[aBase] * sIn[bBase];
             continue;
         }
+        if (VAR == 7) {
+            // MFMA issue-rate ablation: operands stay in registers, no LDS traffic in the loop
+            Frag<MT, NT> f;
+            conv_load_frag<MT, NT, 9>(f, sW, sIn, aBase, bBase, 0);
+#pragma unroll
+            for (int st = 0; st < 9 * (KC / 4); ++st) {
+                conv_mfma_frag<MT, NT>(acc, f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
         if (c < p.nch3)
-            conv_compute_chunk<MT, NT, 9, (VAR == 1 ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
+            conv_compute_chunk<MT, NT, 9, ((VAR == 1 || VAR == 6) ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
         else
-            conv_compute_chunk<MT, NT, 1, (VAR == 1 ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
+            conv_compute_chunk<MT, NT, 1, ((VAR == 1 || VAR == 6) ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
     }
 
     // ---- epilogue: bias, activation, residual, store (C/D layout: col = lane&15 -> pixel,
@@ -295,15 +306,16 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
 // linearly (including the pad floats of every plane); halo / out-of-image / missing-channel
 // elements are fetched from a page of zeros instead of being predicated off.
 // =====================================================================================
-template <int MT, int NT, int PIN>
-__global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p) {
-    using Cfg = ConvCfg<MT, NT>;
-    using G = ConvGeom<NT>;
+template <int MT, int NT, int PIN, int WV>
+__global__ __launch_bounds__(WV * 64, (WV == 16 ? 4 : (WV == 8 ? 4 : 1))) void conv_mfma_dma_kernel(ConvArgs p) {
+    using Cfg = ConvCfg<MT, NT, WV>;
+    using G = ConvGeom<NT, WV>;
+    constexpr int THREADS = WV * 64;
     constexpr int CO_LDS = Cfg::CO_LDS;
-    constexpr int WREGS = Cfg::WREGS;
+    constexpr int WREGS = (Cfg::W3_F4 + THREADS - 1) / THREADS;
     constexpr int PLANE = G::HR * G::RS;
     constexpr int IN_LIN = KC * G::PS;                                   // multiple of 64
-    constexpr int IREGS = (IN_LIN + CONV_THREADS - 1) / CONV_THREADS;
+    constexpr int IREGS = (IN_LIN + THREADS - 1) / THREADS;
     constexpr int BUF = Cfg::LDS_FLOATS;                                 // floats per buffer
     static_assert(IN_LIN % 64 == 0, "input image must be whole wave-instructions");
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: no waterfall loops around the DMA
     const int l16 = lane & 15, kq = lane >> 4;
     const int H = p.H, W = p.W;
     const int HW = H * W;
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p)
     int goff[IREGS];
 #pragma unroll
     for (int i = 0; i < IREGS; ++i) {
-        const int idx = tid + i * CONV_THREADS;
+        const int idx = tid + i * THREADS;
         const int kc = idx / G::PS;
         const int e = idx - kc * G::PS;
         const int r = e / G::RS;
@@ -366,18 +378,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p)
         }
 #pragma unroll
         for (int j = 0; j < WREGS; ++j) {
-            const int i4 = tid + j * CONV_THREADS;
+            const int i4 = tid + j * THREADS;
             if (i4 < n4)
-                __builtin_amdgcn_global_load_lds(wsrc + i4, (lds_ptr)(buf + (j * CONV_THREADS + wave * 64) * 4), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(wsrc + i4, (lds_ptr)(buf + (j * THREADS + wave * 64) * 4), 16, 0, 0);
         }
         float* ibuf = buf + 9 * KC * CO_LDS;
 #pragma unroll
         for (int i = 0; i < IREGS; ++i) {
-            const int idx = tid + i * CONV_THREADS;
+            const int idx = tid + i * THREADS;
             if (idx < IN_LIN) {
                 const int kc = idx / G::PS;
                 const float* g = (goff[i] >= 0 && kc < nvalid) ? sbase + goff[i] : zsrc;
-                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ibuf + i * CONV_THREADS + wave * 64), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ibuf + i * THREADS + wave * 64), 4, 0, 0);
             }
         }
     };
@@ -397,13 +409,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_mfma_dma_kernel(ConvArgs p)
     for (; c < p.nch3; ++c) {              // 3x3 chunks
         float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
-        conv_compute_chunk<MT, NT, 9, PIN>(acc, cur, cur, aBase, bBase);
+        conv_compute_chunk<MT, NT, 9, PIN, WV>(acc, cur, cur, aBase, bBase);
         __syncthreads();                   // everyone done with `cur`; DMA of chunk c+1 has landed
     }
     for (; c < nch; ++c) {                 // fused 1x1 (residual projection) chunks
         float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
-        conv_compute_chunk<MT, NT, 1, PIN>(acc, cur, cur, aBase, bBase);
+        conv_compute_chunk<MT, NT, 1, PIN, WV>(acc, cur, cur, aBase, bBase);
         __syncthreads();
     }
 
@@ -451,9 +463,9 @@ struct ConvTuning {
 };
 inline ConvTuning conv_tuning() {
     static ConvTuning t = [] {
-        ConvTuning r{0, 4};   // nt 0 = pick per launch
+        ConvTuning r{0, -1};   // nt 0 / var -1 = pick per launch
         if (const char* e = getenv("SINDDM_CONV_NT")) r.nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 0);
-        if (const char* e = getenv("SINDDM_CONV_VAR")) r.var = atoi(e) % 6;
+        if (const char* e = getenv("SINDDM_CONV_VAR")) r.var = atoi(e) % 10;   // A/B + ablation knob
         return r;
     }();
     return t;
@@ -465,17 +477,30 @@ inline void conv_launch_t(const ConvArgs& a, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, VAR>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
 }
 
-template <int MT, int NT, int PIN>
+template <int MT, int NT, int PIN, int WV>
 inline void conv_launch_dma_t(const ConvArgs& a, unsigned grid, hipStream_t st) {
-    constexpr size_t lds = 2 * ConvCfg<MT, NT>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_dma_kernel<MT, NT, PIN>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+    constexpr size_t lds = 2 * ConvCfg<MT, NT, WV>::LDS_FLOATS * sizeof(float);
+    hipLaunchKernelGGL((conv_mfma_dma_kernel<MT, NT, PIN, WV>), dim3(grid), dim3(WV * 64), lds, st, a);
 }
 
 template <int MT>
 inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int nt, int var, hipStream_t st) {
+    if (var == 6 || var == 7) {
+        if (nt == 4) { if (var == 6) conv_launch_t<MT, 4, 6>(a, grid, st); else conv_launch_t<MT, 4, 7>(a, grid, st); }
+        else         { if (var == 6) conv_launch_t<MT, 2, 6>(a, grid, st); else conv_launch_t<MT, 2, 7>(a, grid, st); }
+        return;
+    }
+    if (var == 8) {   // 8 waves x (MT x 2) tiles: 8x32 pixel tile, 4 waves/SIMD at 2 workgroups/CU
+        conv_launch_dma_t<MT, 2, 0, 8>(a, grid, st);
+        return;
+    }
+    if (var == 9) {   // 16 waves: 16x32 pixel tile, one workgroup per CU
+        conv_launch_dma_t<MT, 2, 0, 16>(a, grid, st);
+        return;
+    }
     if (var >= 4) {
-        if (nt == 4) { if (var == 5) conv_launch_dma_t<MT, 4, 1>(a, grid, st); else conv_launch_dma_t<MT, 4, 0>(a, grid, st); }
-        else         { if (var == 5) conv_launch_dma_t<MT, 2, 1>(a, grid, st); else conv_launch_dma_t<MT, 2, 0>(a, grid, st); }
+        if (nt == 4) { if (var == 5) conv_launch_dma_t<MT, 4, 1, 4>(a, grid, st); else conv_launch_dma_t<MT, 4, 0, 4>(a, grid, st); }
+        else         { if (var == 5) conv_launch_dma_t<MT, 2, 1, 4>(a, grid, st); else conv_launch_dma_t<MT, 2, 0, 4>(a, grid, st); }
         return;
     }
     if (nt == 4) {
@@ -498,13 +523,17 @@ inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int nt, int var, hi
 inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
     ConvTuning tune = conv_tuning();
-    if (tune.nt == 0) {
-        // 8x32 tiles amortise the weight staging best; fall back to 4x32 tiles when they would not give
-        // every CU at least two rounds of workgroups (small pyramid scales / small batches)
-        const long long blocks8 = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.coblks;
-        tune.nt = blocks8 >= 1024 ? 4 : 2;
+    const long long blocks8 = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.coblks;
+    if (tune.var < 0) {
+        // default: 8-wave workgroups on 8x32 pixel tiles (4 waves/SIMD at 2 workgroups per CU); when
+        // that would leave CUs without two workgroups (coarse pyramid scales, tiny batches) use 4-wave
+        // workgroups on 4x32 tiles instead
+        tune.var = blocks8 >= 512 ? 8 : 4;
+        if (tune.var == 4 && tune.nt == 0) tune.nt = 2;
     }
-    const int TH = tune.nt == 4 ? ConvGeom<4>::TH : ConvGeom<2>::TH;
+    if (tune.nt == 0) tune.nt = blocks8 >= 1024 ? 4 : 2;
+    const int TH = tune.var == 9 ? ConvGeom<2, 16>::TH
+                 : (tune.var == 8 ? ConvGeom<2, 8>::TH : (tune.nt == 4 ? ConvGeom<4>::TH : ConvGeom<2>::TH));
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
     if (rec) {
