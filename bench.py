@@ -119,7 +119,7 @@ def main():
             traffic = json.load(open(tpath)).get("conv_mfma_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<5> (fp32 16x16x4 MFMA implicit-GEMM 3x3 conv)",
+    roofline = {"bound": "mfma", "kernel": "conv_mfma_dma_kernel<5,2,0,8> (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM 3x3 conv, all 8 launches of a step)",
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(conv_n.value),

@@ -186,21 +186,28 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
 // `addt` is added to the result (residual-path gradient).
 // =====================================================================================
 constexpr int DW_TH = 16, DW_TW = 64, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
+constexpr int DW_NX = 4;   // x-tiles per workgroup: all their loads are in flight together (latency-bound otherwise)
 
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
                                                        int cond_stride, const float* __restrict__ addt, int flip,
-                                                       float* __restrict__ out, int C, int H, int W, int tilesX) {
-    __shared__ float tile[DW_HR * DW_RS];
+                                                       float* __restrict__ out, int C, int H, int W, int groupsX) {
+    __shared__ float tile[DW_NX][DW_HR * DW_RS];
     const int c = blockIdx.y, b = blockIdx.z;
-    const int ty = blockIdx.x / tilesX, tx = blockIdx.x - ty * tilesX;
-    const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+    const int ty = blockIdx.x / groupsX, gxi = blockIdx.x - ty * groupsX;
+    const int y0 = ty * DW_TH, xg0 = gxi * (DW_NX * DW_TW);
     const size_t plane = ((size_t)b * C + c) * H * W;
     const float* src = x + plane;
-    for (int i = threadIdx.x; i < DW_HR * DW_RS; i += 256) {
-        const int r = i / DW_RS, cc = i - r * DW_RS;
-        const int gy = y0 + r - 2, gx = x0 + cc - 2;
-        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < DW_NX; ++t) {
+        const int x0 = xg0 + t * DW_TW;
+        if (x0 < W) {
+            for (int i = threadIdx.x; i < DW_HR * DW_RS; i += 256) {
+                const int r = i / DW_RS, cc = i - r * DW_RS;
+                const int gy = y0 + r - 2, gx = x0 + cc - 2;
+                tile[t][i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
+            }
+        }
     }
     float wk[25];
 #pragma unroll
@@ -208,29 +215,34 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     const float add = (bias ? bias[c] : 0.0f) + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float o[4] = {add, add, add, add};
 #pragma unroll
-    for (int dy = 0; dy < 8; ++dy) {
-        float v[5];
+    for (int t = 0; t < DW_NX; ++t) {
+        const int x0 = xg0 + t * DW_TW;
+        if (x0 >= W) break;
+        float o[4] = {add, add, add, add};
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx) v[dx] = tile[(wv * 4 + dy) * DW_RS + lane + dx];
+        for (int dy = 0; dy < 8; ++dy) {
+            float v[5];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ky = dy - r;
-            if (ky >= 0 && ky < 5) {
+            for (int dx = 0; dx < 5; ++dx) v[dx] = tile[t][(wv * 4 + dy) * DW_RS + lane + dx];
 #pragma unroll
-                for (int dx = 0; dx < 5; ++dx) o[r] = fmaf(wk[ky * 5 + dx], v[dx], o[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int ky = dy - r;
+                if (ky >= 0 && ky < 5) {
+#pragma unroll
+                    for (int dx = 0; dx < 5; ++dx) o[r] = fmaf(wk[ky * 5 + dx], v[dx], o[r]);
+                }
             }
         }
-    }
-    const int gx = x0 + lane;
-    if (gx < W) {
+        const int gx = x0 + lane;
+        if (gx < W) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 + wv * 4 + r;
-            if (gy < H) {
-                const size_t oidx = plane + (size_t)gy * W + gx;
-                out[oidx] = addt ? o[r] + addt[oidx] : o[r];
+            for (int r = 0; r < 4; ++r) {
+                const int gy = y0 + wv * 4 + r;
+                if (gy < H) {
+                    const size_t oidx = plane + (size_t)gy * W + gx;
+                    out[oidx] = addt ? o[r] + addt[oidx] : o[r];
+                }
             }
         }
     }
@@ -239,8 +251,9 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
                   const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st) {
     const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
-    hipLaunchKernelGGL(dwconv5_kernel, dim3(tilesX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                       addt, flip, out, C, H, W, tilesX);
+    const int groupsX = (tilesX + DW_NX - 1) / DW_NX;
+    hipLaunchKernelGGL(dwconv5_kernel, dim3(groupsX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
+                       addt, flip, out, C, H, W, groupsX);
     SINDDM_LAUNCH_CHECK();
     return 0;
 }
