@@ -96,8 +96,9 @@ def main():
         img = d._p_sample_host_t(img, t_seq[i], s)
     barrier()
     dt = time.perf_counter() - t0
-    conv_ms, conv_n, conv_fl = C.c_double(), C.c_int64(), C.c_double()
-    _lib.check(lib.sinddm_prof_end(C.byref(conv_ms), C.byref(conv_n), C.byref(conv_fl)), "sinddm_prof_end")
+    conv_ms, conv_n, conv_fl, conv_ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(lib.sinddm_prof_end2(C.byref(conv_ms), C.byref(conv_n), C.byref(conv_fl), C.byref(conv_ex)),
+               "sinddm_prof_end2")
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -107,11 +108,15 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
-    # ---- roofline of the dominant kernel: conv_mfma_kernel (8 launches per step) ----
+    # ---- roofline of the dominant kernels: the MFMA convolutions of the step ----
+    # algorithmic FLOPs = SURVEY 8(d)'s per-pixel figure x pixels per step (direct-convolution count,
+    # also when the Winograd kernel executes only 16/36 of them)
     px = B * H * W
-    alg_flops_per_launch = CONV_FLOP_PER_PIXEL * px / 8.0            # SURVEY 8(d) figure x units per launch
+    launches_per_step = conv_n.value / max(1, args.steps)
+    alg_flops_per_launch = CONV_FLOP_PER_PIXEL * px / max(1.0, launches_per_step)
     avg_launch_ms = conv_ms.value / max(1, conv_n.value)
     achieved = alg_flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+    executed = conv_ex.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -119,9 +124,14 @@ def main():
             traffic = json.load(open(tpath)).get("conv_mfma_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": "conv_mfma_dma_kernel<5,2,0,8> (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM 3x3 conv, all 8 launches of a step)",
+    wino = os.environ.get("SINDDM_CONV_WINO", "1") != "0"
+    roofline = {"bound": "mfma",
+                "kernel": ("conv_wino_kernel<5> (Winograd F(2x2,3x3) on fp32 v_mfma_f32_16x16x4_f32) + conv_mfma_dma_kernel "
+                           "(1x1 projections, C_in=3 conv)" if wino else
+                           "conv_mfma_dma_kernel<5,2,0,8> (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM 3x3 conv)"),
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(conv_n.value),
                 "conv_share_of_step": round(conv_ms.value / (dt * 1e3), 4),
                 "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * args.steps / dt / 1e12, 2)}

@@ -141,6 +141,10 @@ int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* em
  * not thread-safe; off by default.  No reference counterpart (the reference has no profiling). */
 int sinddm_prof_begin(void);
 int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
+/* same, plus the FLOPs the matrix cores actually executed (Winograd F(2x2,3x3) launches execute 16/36
+ * of their algorithmic FLOPs) */
+int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
+                     double* conv_exec_flops_total);
 
 #ifdef __cplusplus
 }

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(WV * 64, (WV == 16 ? 4 : (WV == 8 ? 4 : 1))) void c
 struct ConvProfiler {
     bool on = false;
     int used = 0;
-    double flops = 0.0;
+    double flops = 0.0;        // algorithmic (direct-convolution) FLOPs
+    double exec_flops = 0.0;   // FLOPs the matrix cores actually executed (Winograd: 16/36 of the above)
     static constexpr int MAXREC = 8192;
     hipEvent_t ev[2 * MAXREC];
     int created = 0;
@@ -557,7 +558,9 @@ inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     }
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
-        prof.flops += 2.0 * a.B * a.H * a.W * (double)a.Cout * (9.0 * a.Cin * (a.nch3 > 0) + (double)a.Cin2 * (a.nch1 > 0));
+        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * (9.0 * a.Cin * (a.nch3 > 0) + (double)a.Cin2 * (a.nch1 > 0));
+        prof.flops += fl;
+        prof.exec_flops += fl;
         ++prof.used;
     }
     SINDDM_LAUNCH_CHECK();

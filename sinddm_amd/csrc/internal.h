@@ -9,12 +9,12 @@ struct PackSeg {
     long long count;   // elements in this segment
     long long w;       // source weight offset (conv: [cout][cin][taps]), or bias offset
     long long w2;      // second bias offset to add (-1 none)
-    int kind;          // 0: conv chunks, 1: bias
+    int kind;          // 0: conv chunks, 1: bias, 2: zero page, 3: Winograd-transformed 3x3 weights
     int cin, cout, taps, nch, mt, co_lds;
     int transpose;     // 1: data-gradient image (M = cin of the forward conv, taps flipped)
 };
 struct PackArgs {
-    PackSeg seg[24];
+    PackSeg seg[32];
     int nseg;
     long long total;
 };

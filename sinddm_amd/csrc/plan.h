@@ -23,6 +23,9 @@ struct BlockPlan {
     int nchr;      // residual 1x1 chunks = ceil(cin / KC) or 0
     // packed image offsets (floats)
     int64_t pk_c1, pk_c2, pk_res, pk_b1, pk_b2;
+    // Winograd F(2x2,3x3) images (register layout [coblk][chunk of 16 ci][xi][ks][mt][lane])
+    int nchw1, nchw2;          // 16-channel chunks of conv1 / conv2
+    int64_t pk_wc1, pk_wc2;    // pk_wc1 = -1 when conv1 stays on the direct kernel (C_in < 8)
     int cond_off;  // offset of this block's per-sample bias inside the cond vector
 };
 
@@ -88,6 +91,10 @@ inline NetPlan make_plan(int dim) {
         b.pk_res = q; q += (int64_t)b.coblks * b.nchr * KC * b.co_lds;
         b.pk_b1 = q; q += (int64_t)b.coblks * b.mt * 16;
         b.pk_b2 = q; q += (int64_t)b.coblks * b.mt * 16;
+        b.nchw1 = (b.cin + 15) / 16;
+        b.nchw2 = (b.cout + 15) / 16;
+        if (b.cin >= 8) { b.pk_wc1 = q; q += (int64_t)b.coblks * b.nchw1 * 16 * 4 * b.mt * 64; } else b.pk_wc1 = -1;
+        b.pk_wc2 = q; q += (int64_t)b.coblks * b.nchw2 * 16 * 4 * b.mt * 64;
         b.cond_off = coff;
         coff += b.cin;
     }

@@ -1,6 +1,7 @@
 // Forward path of the SinDDM hot path for gfx950: weight packing, conditioning MLP, depthwise
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
+#include "conv_wino.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -41,6 +42,42 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
             if (co_l < g.mt * 16 && m < g.cin && k < g.cout)
                 v = params[g.w + ((long long)k * g.cin + m) * g.taps + (g.taps - 1 - tap)];
         }
+    } else if (g.kind == 3) {
+        // Winograd F(2x2,3x3): U_xi = G g G^T in the MFMA A-operand register image
+        // [coblk][chunk of 16 ci][xi][ks][mt][lane]; lane -> (co = lane&15, ci = lane>>4)
+        const int lane = (int)(j % 64);
+        long long r = j / 64;
+        const int mt = (int)(r % g.mt); r /= g.mt;
+        const int ks = (int)(r % 4); r /= 4;
+        const int xi = (int)(r % 16); r /= 16;
+        const int ch = (int)(r % g.nch); r /= g.nch;
+        const int cb = (int)r;
+        const int m = cb * g.mt * 16 + mt * 16 + (lane & 15);
+        const int k = ch * 16 + ks * 4 + (lane >> 4);
+        const int M = g.transpose ? g.cin : g.cout;      // rows of THIS conv
+        const int K = g.transpose ? g.cout : g.cin;      // reduction channels of THIS conv
+        if (m < M && k < K) {
+            float gt[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) {
+                    const int tap = a * 3 + b2;
+                    gt[a][b2] = g.transpose ? params[g.w + ((long long)k * g.cin + m) * 9 + (8 - tap)]
+                                            : params[g.w + ((long long)m * g.cin + k) * 9 + tap];
+                }
+            const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+            const int fi = xi >> 2, fj = xi & 3;
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float rowv = 0.f;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) rowv += G[fj][b2] * gt[a][b2];
+                acc += G[fi][a] * rowv;
+            }
+            v = acc;
+        }
     } else if (g.kind == 1) {
         if (j < g.cout) {
             v = params[g.w + j];
@@ -80,6 +117,16 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
             s.w = b.res_w; s.cin = b.cin; s.cout = b.cout; s.taps = 1; s.nch = b.nchr;
             add(s);
         }
+        PackSeg wz{};
+        wz.kind = 3; wz.mt = b.mt; wz.transpose = 0; wz.w2 = -1; wz.taps = 9;
+        if (b.pk_wc1 >= 0) {
+            wz.dst = b.pk_wc1; wz.nch = b.nchw1; wz.count = (long long)b.coblks * b.nchw1 * 16 * 4 * b.mt * 64;
+            wz.w = b.c1_w; wz.cin = b.cin; wz.cout = b.cout;
+            add(wz);
+        }
+        wz.dst = b.pk_wc2; wz.nch = b.nchw2; wz.count = (long long)b.coblks * b.nchw2 * 16 * 4 * b.mt * 64;
+        wz.w = b.c2_w; wz.cin = b.cout; wz.cout = b.cout;
+        add(wz);
         PackSeg t{};
         t.kind = 1; t.cout = b.cout; t.count = (long long)b.coblks * b.mt * 16;
         t.dst = b.pk_b1; t.w = b.c1_b; t.w2 = -1;
@@ -411,20 +458,45 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, P.cond_stride, nullptr, 0,
                                hbuf, B, b.cin, H, W, st);
         if (rc) return rc;
+        const bool wino = wino_enabled();
         ConvArgs c1{};
-        c1.in = hbuf; c1.w3 = packed + b.pk_c1; c1.bias = packed + b.pk_b1; c1.out = gbuf;
-        c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch3 = b.nch1; c1.nch1 = 0;
+        c1.in = hbuf; c1.bias = packed + b.pk_b1; c1.out = gbuf;
+        c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
         c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
-        rc = conv_launch(c1, b.mt, st);
+        if (wino && b.pk_wc1 >= 0) {
+            c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
+            rc = conv_wino_launch(c1, b.mt, st);
+        } else {
+            c1.w3 = packed + b.pk_c1; c1.nch3 = b.nch1;
+            rc = conv_launch(c1, b.mt, st);
+        }
         if (rc) return rc;
         ConvArgs c2{};
-        c2.in = gbuf; c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.out = obuf;
-        c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout; c2.nch3 = b.nch2;
-        if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
-        else { c2.resid = cur; c2.nch1 = 0; }
+        c2.in = gbuf; c2.out = obuf;
+        c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;
         c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
-        rc = conv_launch(c2, b.mt, st);
+        if (wino) {
+            // Winograd 3x3; a 1x1 residual projection runs first on the direct kernel and is added as `resid`
+            if (b.nchr > 0) {
+                ConvArgs r1{};
+                r1.in2 = cur; r1.Cin2 = b.cin; r1.w1 = packed + b.pk_res; r1.nch1 = b.nchr; r1.nch3 = 0;
+                r1.bias = packed + b.pk_b2; r1.out = obuf; r1.Cout = b.cout; r1.coblks = b.coblks;
+                r1.B = B; r1.H = H; r1.W = W; r1.zero = packed + P.pk_zero;
+                rc = conv_launch(r1, b.mt, st);
+                if (rc) return rc;
+                c2.resid = obuf; c2.bias = nullptr;          // in place: each thread reads resid[o] before writing out[o]
+            } else {
+                c2.resid = cur; c2.bias = packed + b.pk_b2;
+            }
+            c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2; c2.nch1 = 0;
+            rc = conv_wino_launch(c2, b.mt, st);
+        } else {
+            c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.nch3 = b.nch2;
+            if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
+            else { c2.resid = cur; c2.nch1 = 0; }
+            rc = conv_launch(c2, b.mt, st);
+        }
         if (rc) return rc;
         cur = obuf;
         curb = sel[2];
@@ -510,10 +582,16 @@ int sinddm_prof_begin(void) {
     p.on = true;
     p.used = 0;
     p.flops = 0.0;
+    p.exec_flops = 0.0;
     return 0;
 }
 
 int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total) {
+    return sinddm_prof_end2(conv_ms_total, conv_launches, conv_flops_total, nullptr);
+}
+
+int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
+                     double* conv_exec_flops_total) {
     ConvProfiler& p = conv_profiler();
     p.on = false;
     double ms = 0.0;
@@ -528,6 +606,7 @@ int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_
     if (conv_ms_total) *conv_ms_total = ms;
     if (conv_launches) *conv_launches = p.used;
     if (conv_flops_total) *conv_flops_total = p.flops;
+    if (conv_exec_flops_total) *conv_exec_flops_total = p.exec_flops;
     p.used = 0;
     return 0;
 }
