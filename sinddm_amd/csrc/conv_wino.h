@@ -25,17 +25,27 @@ namespace sinddm {
 
 constexpr int WN_THREADS = 1024;
 constexpr int WN_KC = 16;                      // input channels per chunk (4 k-steps)
-constexpr int WN_TH = 8, WN_TW = 32;
-constexpr int WN_RS = WN_TW + 2, WN_HR = WN_TH + 2;
-constexpr int WN_PLANE = WN_HR * WN_RS;        // 340
-constexpr int WN_PS = WN_PLANE + 1;            // 341: odd -> conflict-free stride-2 reads across the k lanes
-constexpr int WN_IN_LIN = WN_KC * WN_PS;       // 5456 floats per buffer
-constexpr int WN_IREGS = (WN_IN_LIN + WN_THREADS - 1) / WN_THREADS;   // 6
-constexpr int WN_MSTRIDE = 65;                 // [xi][16 co][64 tiles + 1]
-constexpr int WN_LDS_FLOATS = (2 * WN_IN_LIN > 16 * 16 * WN_MSTRIDE) ? 2 * WN_IN_LIN : 16 * 16 * WN_MSTRIDE;
+constexpr int WN_TW = 32;
+constexpr int WN_RS = WN_TW + 2;
+// geometry for NTR tile-rows (2 pixel rows each) per workgroup
+template <int NTR>
+struct WinoGeom {
+    static constexpr int TH = 2 * NTR;
+    static constexpr int HR = TH + 2;
+    static constexpr int PLANE = HR * WN_RS;
+    static constexpr int PS = (PLANE % 2) ? PLANE : PLANE + 1;   // odd -> conflict-free stride-2 reads across the k lanes
+    static constexpr int IN_LIN = WN_KC * PS;                    // floats per buffer
+    static constexpr int IREGS = (IN_LIN + WN_THREADS - 1) / WN_THREADS;
+    static constexpr int NTILES = NTR * 16;
+    static constexpr int MSTRIDE = NTILES + 1;                   // [xi][16 co][tiles + 1]
+    static constexpr int LDS_FLOATS = (2 * IN_LIN > 16 * 16 * MSTRIDE) ? 2 * IN_LIN : 16 * 16 * MSTRIDE;
+};
 
-template <int MT>
+template <int MT, int NTR>
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
+    using WG = WinoGeom<NTR>;
+    constexpr int WN_TH = WG::TH, WN_PLANE = WG::PLANE, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
+    constexpr int WN_IREGS = WG::IREGS, WN_MSTRIDE = WG::MSTRIDE;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -95,7 +105,8 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, nvalid * HW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WN_IREGS; ++i) {
-            const int idx = tid + i * WN_THREADS;
+            int idx = tid + i * WN_THREADS;
+            asm volatile("" : "+v"(idx));      // keep the offset computation inside the chunk loop (no LICM -> no spill)
             if (idx < WN_IN_LIN)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(buf + i * WN_THREADS + xi * 64), 4, src_off(idx), 0, 0, 0);
         }
@@ -118,11 +129,11 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
     load_w(0, 0, 0);
     load_w(1, 0, 1);
 
-    f32x4 acc[MT][4];
+    f32x4 acc[MT][NTR];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTR; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     issue(0, smem);
     __syncthreads();
@@ -138,17 +149,14 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
         if (c > 0) load_w(1, c, 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            float bv[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NTR; ++nt) {
                 const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
-                bv[nt] = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
+                const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv[nt], acc[mt][nt], 0, 0, 0);
             if (ks == 0) load_w(0, c, 2);
             if (ks == 1) {
                 load_w(1, c, 3);
@@ -167,17 +175,18 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
     for (int mt = 0; mt < MT; ++mt) {
         // C layout: col = lane&15 -> tile-col, row = (lane>>4)*4 + r -> channel within the M tile
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTR; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sM[(xi * 16 + kq * 4 + r) * WN_MSTRIDE + nt * 16 + l16] = acc[mt][nt][r];
         __syncthreads();
         float m[16];
+        const int lt = lane < WG::NTILES ? lane : 0;     // (NTR = 3: the last 16 lanes have no tile)
 #pragma unroll
-        for (int f = 0; f < 16; ++f) m[f] = sM[(f * 16 + cl) * WN_MSTRIDE + lane];
+        for (int f = 0; f < 16; ++f) m[f] = sM[(f * 16 + cl) * WN_MSTRIDE + lt];
         __syncthreads();
         const int col = mt * 16 + cl;
         const int co = cb * (MT * 16) + col;
-        if (co < p.Cout) {
+        if (co < p.Cout && lane < WG::NTILES) {
             // t[p][j] = sum_i A^T[p][i] m[i][j];  Y[p][q] = sum_j t[p][j] A^T[q][j]
             float t0[4], t1[4];
 #pragma unroll
@@ -213,8 +222,29 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
     }
 }
 
+inline int wino_ntr() {
+    static int v = [] {
+        const char* e = getenv("SINDDM_WINO_NTR");
+        const int n = e ? atoi(e) : 3;
+        return n == 4 ? 4 : 3;
+    }();
+    return v;
+}
+
+template <int MT>
+inline void conv_wino_launch_t(const ConvArgs& a, unsigned grid, int ntr, hipStream_t st) {
+    if (ntr == 4) {
+        constexpr size_t lds = WinoGeom<4>::LDS_FLOATS * sizeof(float);
+        hipLaunchKernelGGL((conv_wino_kernel<MT, 4>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    } else {
+        constexpr size_t lds = WinoGeom<3>::LDS_FLOATS * sizeof(float);
+        hipLaunchKernelGGL((conv_wino_kernel<MT, 3>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+    }
+}
+
 inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
+    const int ntr = wino_ntr();
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
     if (rec) {
@@ -225,16 +255,16 @@ inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
         }
         (void)hipEventRecord(prof.ev[2 * prof.used], st);
     }
+    const int TH = 2 * ntr;
     a.tilesX = (a.W + WN_TW - 1) / WN_TW;
-    a.tilesY = (a.H + WN_TH - 1) / WN_TH;
+    a.tilesY = (a.H + TH - 1) / TH;
     a.ntiles = a.B * a.tilesX * a.tilesY;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     const unsigned grid = (unsigned)(a.tiles_per_xcd * 8 * a.coblks);
-    constexpr size_t lds = WN_LDS_FLOATS * sizeof(float);
     switch (mt) {
-        case 5: hipLaunchKernelGGL(conv_wino_kernel<5>, dim3(grid), dim3(WN_THREADS), lds, st, a); break;
-        case 2: hipLaunchKernelGGL(conv_wino_kernel<2>, dim3(grid), dim3(WN_THREADS), lds, st, a); break;
-        case 1: hipLaunchKernelGGL(conv_wino_kernel<1>, dim3(grid), dim3(WN_THREADS), lds, st, a); break;
+        case 5: conv_wino_launch_t<5>(a, grid, ntr, st); break;
+        case 2: conv_wino_launch_t<2>(a, grid, ntr, st); break;
+        case 1: conv_wino_launch_t<1>(a, grid, ntr, st); break;
         default: return SINDDM_E_BADSHAPE;
     }
     if (rec) {
