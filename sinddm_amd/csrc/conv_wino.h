@@ -34,34 +34,46 @@ struct WinoGeom {
     static constexpr int HR = TH + 2;
     static constexpr int PLANE = HR * WN_RS;
     static constexpr int PS = (PLANE % 2) ? PLANE : PLANE + 1;   // odd -> conflict-free stride-2 reads across the k lanes
-    static constexpr int IN_LIN = WN_KC * PS;                    // floats per buffer
-    static constexpr int IREGS = (IN_LIN + WN_THREADS - 1) / WN_THREADS;
+    static constexpr int IN_LIN = WN_KC * PS;                    // floats per raw-tile buffer
+    static constexpr int RAW_FLOATS = (2 * IN_LIN + 3) / 4 * 4;  // two buffers
     static constexpr int NTILES = NTR * 16;
-    static constexpr int MSTRIDE = NTILES + 1;                   // [xi][16 co][tiles + 1]
-    static constexpr int LDS_FLOATS = (2 * IN_LIN > 16 * 16 * MSTRIDE) ? 2 * IN_LIN : 16 * 16 * MSTRIDE;
+    static constexpr int MSTRIDE = NTILES + 1;                   // [xi][co][tiles + 1]
+    // M tiles (16 channels each) exchanged per epilogue pass: two if the LDS budget (160 KB) allows
+    static constexpr int MPP = ((RAW_FLOATS + 16 * 32 * MSTRIDE) * 4 <= 160 * 1024) ? 2 : 1;
+    static constexpr int LDS_FLOATS = RAW_FLOATS + 16 * (16 * MPP) * MSTRIDE;
 };
 
-template <int MT, int NTR>
-__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
+struct WinoItem {          // one unit of work: an (8|6)x32 pixel tile x one block of MT*16 output channels
+    int b, y0, x0, cb;
+};
+
+template <int MT, int NTR, int ACT>
+__global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
     using WG = WinoGeom<NTR>;
     constexpr int WN_TH = WG::TH, WN_PLANE = WG::PLANE, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
-    constexpr int WN_IREGS = WG::IREGS, WN_MSTRIDE = WG::MSTRIDE;
+    constexpr int WN_MSTRIDE = WG::MSTRIDE, MPP = WG::MPP;
+    constexpr int WN_IREGS = (WN_IN_LIN + WN_THREADS - 1) / WN_THREADS;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sM = smem + WG::RAW_FLOATS;       // epilogue exchange area, disjoint from the raw-tile buffers
 
-    const int id = blockIdx.x;
-    const int xcd = id & 7;
-    const int slot = id >> 3;
-    const int cb = slot % p.coblks;
-    const int tl = slot / p.coblks;
-    const int tile = xcd * p.tiles_per_xcd + tl;
-    if (tile >= p.ntiles) return;
+    // persistent workgroup: XCD `xcd` owns a contiguous range of tiles (its L2 serves their halos and both
+    // output-channel blocks of a tile); workgroup `ls` of that XCD takes items ls, ls + wg_per_xcd, ...
+    const int xcd = blockIdx.x & 7;
+    const int ls = blockIdx.x >> 3;
     const int tpi = p.tilesX * p.tilesY;
-    const int b = tile / tpi;
-    const int trm = tile - b * tpi;
-    const int ty = trm / p.tilesX;
-    const int tx = trm - ty * p.tilesX;
-    const int y0 = ty * WN_TH, x0 = tx * WN_TW;
+    auto decode = [&](int l, WinoItem& it) -> bool {
+        if (l >= items_per_xcd) return false;
+        const int tile = xcd * p.tiles_per_xcd + l / p.coblks;
+        if (tile >= p.ntiles) return false;
+        it.cb = l % p.coblks;
+        it.b = tile / tpi;
+        const int trm = tile - it.b * tpi;
+        const int ty = trm / p.tilesX;
+        it.y0 = ty * WN_TH;
+        it.x0 = (trm - ty * p.tilesX) * WN_TW;
+        return true;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,143 +94,189 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p) {
     const int o00 = lbase + pa0 * WN_RS + pb0, o01 = lbase + pa0 * WN_RS + pb1;
     const int o10 = lbase + pa1 * WN_RS + pb0, o11 = lbase + pa1 * WN_RS + pb1;
 
-    // raw-tile staging map: element idx of the linear LDS image [kc][WN_PS] -> byte offset inside the chunk's
-    // channel block, or -1 (out of range -> the buffer bounds check returns 0).  Recomputed at every issue
-    // (a dozen VALU ops per element) instead of being held in registers: the kernel is register-bound.
-    auto src_off = [&](int idx) -> int {
-        const int kc = idx / WN_PS;
-        const int e = idx - kc * WN_PS;
-        const int r = e / WN_RS;
-        const int c = e - r * WN_RS;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = e < WN_PLANE && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        return ok ? (kc * HW + gy * W + gx) * 4 : -1;
-    };
     const int nch = p.nch3;                                        // 16-channel chunks
-    auto issue = [&](int c, float* buf) {
+    // raw-tile DMA of chunk c of item `it`: element idx of the linear LDS image [kc][WN_PS] -> byte offset inside
+    // the chunk's channel block, or -1 (out of range -> the buffer bounds check returns 0: halo outside the image,
+    // channels past C_in, plane pad).  Offsets are recomputed at every issue (the kernel is register-bound).
+    auto issue = [&](const WinoItem& it, int c, float* buf) {
         const int ch0 = c * WN_KC;
-        const float* sbase = p.in + ((size_t)b * p.Cin + ch0) * HW;
+        const float* sbase = p.in + ((size_t)it.b * p.Cin + ch0) * HW;
         const int nvalid = (p.Cin - ch0) < WN_KC ? (p.Cin - ch0) : WN_KC;
-        // buffer descriptor over the channels of this chunk that exist: every out-of-range offset (halo outside
-        // the image = -1, channels past C_in, plane pad) is zero-filled by the bounds check, no select needed
         const __amdgpu_buffer_rsrc_t rs =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, nvalid * HW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WN_IREGS; ++i) {
             int idx = tid + i * WN_THREADS;
-            asm volatile("" : "+v"(idx));      // keep the offset computation inside the chunk loop (no LICM -> no spill)
-            if (idx < WN_IN_LIN)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(buf + i * WN_THREADS + xi * 64), 4, src_off(idx), 0, 0, 0);
+            asm volatile("" : "+v"(idx));      // keep the offset computation inside the loop (no LICM -> no spill)
+            if (idx < WN_IN_LIN) {
+                const int kc = idx / WN_PS;
+                const int e = idx - kc * WN_PS;
+                const int r = e / WN_RS;
+                const int cc = e - r * WN_RS;
+                const int gy = it.y0 + r - 1, gx = it.x0 + cc - 1;
+                const bool ok = e < WN_PLANE && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const int off = ok ? (kc * HW + gy * W + gx) * 4 : -1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(buf + i * WN_THREADS + xi * 64), 4, off, 0, 0, 0);
+            }
         }
     };
     // weights: register image [coblk][chunk][xi][ks][mt][lane], streamed with buffer loads
-    // (uniform descriptor + scalar chunk offset + lane*4: no 64-bit vector address arithmetic)
+    // (uniform descriptor + scalar offset + lane*4: no 64-bit vector address arithmetic)
     const __amdgpu_buffer_rsrc_t rsw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFFC, 0x00020000);
     const int wlane = lane * 4;
-    const int wblk = ((cb * nch) * 16 + xi) * (4 * MT * 64) * 4;          // bytes, wave-uniform
     constexpr int WCHUNK_B = 16 * 4 * MT * 64 * 4;
     // weight registers: a ring of two k-step slots (MT registers each); slot (ks & 1) holds k-step ks
     float w[2][MT];
-    auto load_w = [&](int slot, int c, int ks) {
-        const int so = wblk + c * WCHUNK_B + ks * (MT * 64 * 4);
+    auto load_w = [&](int slot, int cb, int c, int ks) {
+        const int so = ((cb * nch + c) * 16 + xi) * (4 * MT * 64 * 4) + ks * (MT * 64 * 4);
+        (void)WCHUNK_B;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             w[slot][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsw, wlane, so + mt * 256, 0));
     };
-    load_w(0, 0, 0);
-    load_w(1, 0, 1);
 
-    f32x4 acc[MT][NTR];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTR; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    issue(0, smem);
+    const int abl = p.act >> 8;          // timing ablations (diagnostics only): 1 = no epilogue, 2 = no main loop
+    WinoItem it;
+    int l = ls;
+    if (!decode(l, it)) return;
+    load_w(0, it.cb, 0, 0);
+    load_w(1, it.cb, 0, 1);
+    issue(it, 0, smem);
     __syncthreads();
-    // Schedule inside a chunk.  All 16 waves of the CU meet at the barrier at the end of every chunk, so
-    // nothing young may be in flight there (the barrier carries a vmcnt(0) because of the LDS DMA):
-    //   after k-step 0: load k-step 2 of this chunk          (slot 0)
-    //   after k-step 1: load k-step 3 of this chunk (slot 1); issue the raw-tile DMA of the next chunk
-    //   after k-step 2: load k-step 0 of the next chunk      (slot 0)
-    //   k-step 3, barrier, then load k-step 1 of the next chunk (slot 1) -- needed one k-step later
-    for (int c = 0; c < nch; ++c) {
-        const float* cur = smem + (c & 1) * WN_IN_LIN;
-        const bool more = c + 1 < nch;
-        if (c > 0) load_w(1, c, 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int nt = 0; nt < NTR; ++nt) {
-                const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
-                const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
-            }
-            if (ks == 0) load_w(0, c, 2);
-            if (ks == 1) {
-                load_w(1, c, 3);
-                if (more) issue(c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
-            }
-            if (ks == 2 && more) load_w(0, c + 1, 0);
-        }
-        __syncthreads();
-    }
 
-    // ---- output transform + epilogue, one 16-channel M tile per pass ----
-    float* sM = smem;
-    const int cl = xi;                       // pass-2 role: this wave handles channel `cl` of the M tile
-    const int tr = lane >> 4, tc = lane & 15;   // lane = 2x2 tile (tile-row, tile-col)
+    const int tr = lane >> 4, tc = lane & 15;   // epilogue role of a lane: 2x2 tile (tile-row, tile-col)
+    const int lt = lane < WG::NTILES ? lane : 0;
+
+    for (;;) {
+        f32x4 acc[MT][NTR];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        // C layout: col = lane&15 -> tile-col, row = (lane>>4)*4 + r -> channel within the M tile
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NTR; ++nt)
+            for (int nt = 0; nt < NTR; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // Schedule inside a chunk.  All 16 waves of the CU meet at the barrier at the end of every chunk, so
+        // nothing young may be in flight there (the barrier carries a vmcnt(0) because of the LDS DMA):
+        //   after k-step 0: load k-step 2 of this chunk          (slot 0)
+        //   after k-step 1: load k-step 3 of this chunk (slot 1); issue the raw-tile DMA of the next chunk
+        //   after k-step 2: load k-step 0 of the next chunk      (slot 0)
+        //   k-step 3, barrier, then load k-step 1 of the next chunk (slot 1) -- needed one k-step later
+        for (int c = 0; c < ((abl & 2) ? 1 : nch); ++c) {
+            const float* cur = smem + (c & 1) * WN_IN_LIN;
+            const bool more = c + 1 < nch;
+            if (c > 0) load_w(1, it.cb, c, 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sM[(xi * 16 + kq * 4 + r) * WN_MSTRIDE + nt * 16 + l16] = acc[mt][nt][r];
-        __syncthreads();
-        float m[16];
-        const int lt = lane < WG::NTILES ? lane : 0;     // (NTR = 3: the last 16 lanes have no tile)
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) m[f] = sM[(f * 16 + cl) * WN_MSTRIDE + lt];
-        __syncthreads();
-        const int col = mt * 16 + cl;
-        const int co = cb * (MT * 16) + col;
-        if (co < p.Cout && lane < WG::NTILES) {
-            // t[p][j] = sum_i A^T[p][i] m[i][j];  Y[p][q] = sum_j t[p][j] A^T[q][j]
-            float t0[4], t1[4];
+                for (int nt = 0; nt < NTR; ++nt) {
+                    const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
+                    const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
-                t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
+                }
+                if (ks == 0) load_w(0, it.cb, c, 2);
+                if (ks == 1) {
+                    load_w(1, it.cb, c, 3);
+                    if (more) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
+                }
+                if (ks == 2 && more) load_w(0, it.cb, c + 1, 0);
             }
-            float yv[2][2];
-            yv[0][0] = t0[0] + t0[1] + t0[2];
-            yv[0][1] = t0[1] - t0[2] - t0[3];
-            yv[1][0] = t1[0] + t1[1] + t1[2];
-            yv[1][1] = t1[1] - t1[2] - t1[3];
-            const float bvs = p.bias ? p.bias[cb * (MT * 16) + col] : 0.0f;
-            const size_t cbase = ((size_t)b * p.Cout + co) * HW;
+            __syncthreads();
+        }
+
+        // next work item: start its first raw tile and weight registers now, so that they arrive while this
+        // item's epilogue runs (raw buffer 0 is free: every wave passed the last chunk barrier)
+        WinoItem nx;
+        l += wg_per_xcd;
+        const bool have_next = decode(l, nx);
+        if (have_next) {
+            load_w(0, nx.cb, 0, 0);
+            load_w(1, nx.cb, 0, 1);
+            issue(nx, 0, smem);
+        }
+
+        if (!(abl & 1)) {
+            // ---- output transform + epilogue, MPP 16-channel M tiles per pass ----
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int y = y0 + 2 * tr + pp;
+            for (int m0 = 0; m0 < MT; m0 += MPP) {
+                // C layout: col = lane&15 -> tile-col, row = (lane>>4)*4 + r -> channel within the M tile
 #pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int x = x0 + 2 * tc + qq;
-                    if (y < H && x < W) {
-                        const size_t o = cbase + (size_t)y * W + x;
-                        float v = yv[pp][qq] + bvs;
-                        if (p.out_pre) p.out_pre[o] = v;
-                        if (p.act == 1) v = gelu_erf(v);
-                        else if (p.act == 2) v *= gelu_erf_grad(p.aux[o]);
-                        if (p.resid) v += p.resid[o];
-                        p.out[o] = v;
+                for (int h = 0; h < MPP; ++h) {
+                    if (m0 + h < MT) {
+#pragma unroll
+                        for (int nt = 0; nt < NTR; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                sM[(xi * (16 * MPP) + h * 16 + kq * 4 + r) * WN_MSTRIDE + nt * 16 + l16] = acc[m0 + h][nt][r];
                     }
                 }
+                // residual operands of this pass are fetched before the exchange so that their latency overlaps it
+                float rs_v[MPP][4];
+                size_t obase[MPP];
+#pragma unroll
+                for (int h = 0; h < MPP; ++h) {
+                    const int co = it.cb * (MT * 16) + (m0 + h) * 16 + xi;
+                    obase[h] = ((size_t)it.b * p.Cout + co) * HW + (size_t)(it.y0 + 2 * tr) * W + it.x0 + 2 * tc;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rs_v[h][k] = 0.f;
+                    if (p.resid && m0 + h < MT && co < p.Cout && lane < WG::NTILES) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int y = it.y0 + 2 * tr + (k >> 1), x = it.x0 + 2 * tc + (k & 1);
+                            if (y < H && x < W) rs_v[h][k] = p.resid[obase[h] + (size_t)(k >> 1) * W + (k & 1)];
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < MPP; ++h) {
+                    if (m0 + h >= MT) break;
+                    const int col = (m0 + h) * 16 + xi;              // this wave's channel of the M tile
+                    const int co = it.cb * (MT * 16) + col;
+                    float m[16];
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) m[f] = sM[(f * (16 * MPP) + h * 16 + xi) * WN_MSTRIDE + lt];
+                    if (co < p.Cout && lane < WG::NTILES) {
+                        // t[p][j] = sum_i A^T[p][i] m[i][j];  Y[p][q] = sum_j t[p][j] A^T[q][j]
+                        float t0[4], t1[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            t0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                            t1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+                        }
+                        float yv[4];
+                        yv[0] = t0[0] + t0[1] + t0[2];
+                        yv[1] = t0[1] - t0[2] - t0[3];
+                        yv[2] = t1[0] + t1[1] + t1[2];
+                        yv[3] = t1[1] - t1[2] - t1[3];
+                        const float bvs = p.bias ? p.bias[it.cb * (MT * 16) + col] : 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int y = it.y0 + 2 * tr + (k >> 1), x = it.x0 + 2 * tc + (k & 1);
+                            if (y < H && x < W) {
+                                const size_t o = obase[h] + (size_t)(k >> 1) * W + (k & 1);
+                                float v = yv[k] + bvs;
+                                if (ACT == 1) {
+                                    if (p.out_pre) p.out_pre[o] = v;
+                                    v = gelu_erf(v);
+                                } else if (ACT == 2) {
+                                    v *= gelu_erf_grad(p.aux[o]);
+                                }
+                                v += rs_v[h][k];
+                                p.out[o] = v;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
             }
+        } else {
+            if (acc[0][0][0] == 123.456f) p.out[tid] = acc[0][0][1];     // keep the accumulators alive
+            __syncthreads();
         }
+        if (!have_next) break;
+        it = nx;
     }
 }
 
@@ -231,19 +289,38 @@ inline int wino_ntr() {
     return v;
 }
 
-template <int MT>
-inline void conv_wino_launch_t(const ConvArgs& a, unsigned grid, int ntr, hipStream_t st) {
-    if (ntr == 4) {
-        constexpr size_t lds = WinoGeom<4>::LDS_FLOATS * sizeof(float);
-        hipLaunchKernelGGL((conv_wino_kernel<MT, 4>), dim3(grid), dim3(WN_THREADS), lds, st, a);
-    } else {
-        constexpr size_t lds = WinoGeom<3>::LDS_FLOATS * sizeof(float);
-        hipLaunchKernelGGL((conv_wino_kernel<MT, 3>), dim3(grid), dim3(WN_THREADS), lds, st, a);
+template <int MT, int NTR>
+inline void conv_wino_launch_a(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
+    constexpr size_t lds = WinoGeom<NTR>::LDS_FLOATS * sizeof(float);
+    switch (a.act & 0xff) {
+        case 1: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 1>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
+        case 2: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 2>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
+        default: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 0>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx);
     }
+}
+
+template <int MT>
+inline void conv_wino_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, int ntr, hipStream_t st) {
+    if (ntr == 4) conv_wino_launch_a<MT, 4>(a, grid, ipx, wpx, st);
+    else conv_wino_launch_a<MT, 3>(a, grid, ipx, wpx, st);
+}
+
+inline int device_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
 }
 
 inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
+    {
+        static int abl = [] { const char* e = getenv("SINDDM_WINO_ABL"); return e ? atoi(e) : 0; }();
+        a.act |= abl << 8;
+    }
     const int ntr = wino_ntr();
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
@@ -260,11 +337,17 @@ inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     a.tilesY = (a.H + TH - 1) / TH;
     a.ntiles = a.B * a.tilesX * a.tilesY;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
-    const unsigned grid = (unsigned)(a.tiles_per_xcd * 8 * a.coblks);
+    // persistent launch: one 16-wave workgroup per CU (its registers and LDS fill the CU), each walking its
+    // share of the XCD's work items
+    const int ipx = a.tiles_per_xcd * a.coblks;                  // work items per XCD
+    int wpx = device_cu_count() / 8;                             // workgroups per XCD
+    if (wpx < 1) wpx = 1;
+    if (wpx > ipx) wpx = ipx;
+    const unsigned grid = (unsigned)(wpx * 8);
     switch (mt) {
-        case 5: conv_wino_launch_t<5>(a, grid, ntr, st); break;
-        case 2: conv_wino_launch_t<2>(a, grid, ntr, st); break;
-        case 1: conv_wino_launch_t<1>(a, grid, ntr, st); break;
+        case 5: conv_wino_launch_t<5>(a, grid, ipx, wpx, ntr, st); break;
+        case 2: conv_wino_launch_t<2>(a, grid, ipx, wpx, ntr, st); break;
+        case 1: conv_wino_launch_t<1>(a, grid, ipx, wpx, ntr, st); break;
         default: return SINDDM_E_BADSHAPE;
     }
     if (rec) {
