@@ -52,7 +52,6 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     using WG = WinoGeom<NTR>;
     constexpr int WN_TH = WG::TH, WN_PLANE = WG::PLANE, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
     constexpr int WN_MSTRIDE = WG::MSTRIDE, MPP = WG::MPP;
-    constexpr int WN_IREGS = (WN_IN_LIN + WN_THREADS - 1) / WN_THREADS;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sM = smem + WG::RAW_FLOATS;       // epilogue exchange area, disjoint from the raw-tile buffers
@@ -95,28 +94,26 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     const int o10 = lbase + pa1 * WN_RS + pb0, o11 = lbase + pa1 * WN_RS + pb1;
 
     const int nch = p.nch3;                                        // 16-channel chunks
-    // raw-tile DMA of chunk c of item `it`: element idx of the linear LDS image [kc][WN_PS] -> byte offset inside
-    // the chunk's channel block, or -1 (out of range -> the buffer bounds check returns 0: halo outside the image,
-    // channels past C_in, plane pad).  Offsets are recomputed at every issue (the kernel is register-bound).
+    // raw-tile DMA of chunk c of item `it`.  Wave w stages channel w of the 16-channel chunk: one LDS-DMA wave
+    // instruction per tile row (34 active lanes -> 34 consecutive LDS floats).  The buffer descriptor covers exactly
+    // that channel plane (0 bytes if the channel does not exist), so everything outside the image -- halo rows and
+    // columns, missing channels -- is zero-filled by the hardware bounds check: out-of-range lanes/rows simply
+    // carry an offset >= 2^30.  Per instruction: one scalar row offset + one v_add.
+    constexpr unsigned OOB = 0x40000000u;
     auto issue = [&](const WinoItem& it, int c, float* buf) {
-        const int ch0 = c * WN_KC;
-        const float* sbase = p.in + ((size_t)it.b * p.Cin + ch0) * HW;
-        const int nvalid = (p.Cin - ch0) < WN_KC ? (p.Cin - ch0) : WN_KC;
+        const int ch = c * WN_KC + xi;
+        const float* sbase = p.in + ((size_t)it.b * p.Cin + (ch < p.Cin ? ch : 0)) * HW;
         const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, nvalid * HW * 4, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, ch < p.Cin ? HW * 4 : 0, 0x00020000);
+        if (lane < WN_RS) {
+            const int gx = it.x0 + lane - 1;
+            const unsigned loff = (gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
+            float* pl = buf + xi * WN_PS;
 #pragma unroll
-        for (int i = 0; i < WN_IREGS; ++i) {
-            int idx = tid + i * WN_THREADS;
-            asm volatile("" : "+v"(idx));      // keep the offset computation inside the loop (no LICM -> no spill)
-            if (idx < WN_IN_LIN) {
-                const int kc = idx / WN_PS;
-                const int e = idx - kc * WN_PS;
-                const int r = e / WN_RS;
-                const int cc = e - r * WN_RS;
-                const int gy = it.y0 + r - 1, gx = it.x0 + cc - 1;
-                const bool ok = e < WN_PLANE && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const int off = ok ? (kc * HW + gy * W + gx) * 4 : -1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(buf + i * WN_THREADS + xi * 64), 4, off, 0, 0, 0);
+            for (int r = 0; r < WG::HR; ++r) {
+                const int gy = it.y0 + r - 1;
+                const unsigned roff = (gy >= 0 && gy < H) ? (unsigned)(gy * W) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(pl + r * WN_RS), 4, (int)(loff + roff), 0, 0, 0);
             }
         }
     };
@@ -128,7 +125,10 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     constexpr int WCHUNK_B = 16 * 4 * MT * 64 * 4;
     // weight registers: a ring of two k-step slots (MT registers each); slot (ks & 1) holds k-step ks
     float w[2][MT];
+    const int abl = p.act >> 8;          // timing ablations (diagnostics only): 1 = no epilogue, 2 = no main loop,
+                                         // 4 = weights loaded once (no streaming), 8 = no raw-tile DMA after the first
     auto load_w = [&](int slot, int cb, int c, int ks) {
+        if ((abl & 4) && c > 0) return;
         const int so = ((cb * nch + c) * 16 + xi) * (4 * MT * 64 * 4) + ks * (MT * 64 * 4);
         (void)WCHUNK_B;
 #pragma unroll
@@ -136,7 +136,6 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
             w[slot][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsw, wlane, so + mt * 256, 0));
     };
 
-    const int abl = p.act >> 8;          // timing ablations (diagnostics only): 1 = no epilogue, 2 = no main loop
     WinoItem it;
     int l = ls;
     if (!decode(l, it)) return;
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
                 if (ks == 0) load_w(0, it.cb, c, 2);
                 if (ks == 1) {
                     load_w(1, it.cb, c, 3);
-                    if (more) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
+                    if (more && !(abl & 8)) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
                 }
                 if (ks == 2 && more) load_w(0, it.cb, c + 1, 0);
             }
