@@ -4,6 +4,7 @@
 // Replaces autograd through SinDDMNet + torch.optim.Adam + EMA of the reference
 // (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
 #include "conv_mfma.h"
+#include "conv_wino.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 struct BwdPack {
     // per block: dgrad of conv2 (cout->cout), dgrad of conv1 (cout->cin), dgrad of res 1x1 (cout->cin)
     long long dg2[4], dg1[4], dres[4], dfin, zero;
+    long long wdg2[4], wdg1[4];     // Winograd images of the 3x3 data-gradient convs (wdg1 = -1: stays direct)
     long long total;
     int mt2[4], mt1[4], cb2[4], cb1[4];
     int mtf, cbf;
@@ -467,6 +469,13 @@ static BwdPack make_bwd_pack(const NetPlan& P) {
     }
     k.mtf = mt_for(P.half); k.cbf = (P.half + k.mtf * 16 - 1) / (k.mtf * 16);
     k.dfin = q; q += (long long)k.cbf * 1 * KC * co_lds_for(k.mtf);     // K = 3 channels -> one chunk
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        const int nchW = (b.cout + 15) / 16;
+        k.wdg2[l] = q; q += (long long)k.cb2[l] * nchW * 16 * 4 * k.mt2[l] * 64;
+        if (b.cin >= 8) { k.wdg1[l] = q; q += (long long)k.cb1[l] * nchW * 16 * 4 * k.mt1[l] * 64; }
+        else k.wdg1[l] = -1;
+    }
     k.zero = q; q += 64;
     k.total = q;
     return k;
@@ -493,6 +502,20 @@ static int pack_backward(const NetPlan& P, const float* params, float* packed, h
         if (b.res_w >= 0) add(k.dres[l], b.res_w, b.cin, b.cout, 1, k.mt1[l], k.cb1[l]);
     }
     add(k.dfin, P.fin_w, P.half, CHANNELS, 1, k.mtf, k.cbf);
+    auto addw = [&](long long dst, long long w, int fcin, int fcout, int mt, int coblks) {
+        PackSeg s{};
+        s.kind = 3; s.transpose = 1; s.w2 = -1; s.taps = 9;
+        s.dst = dst; s.w = w; s.cin = fcin; s.cout = fcout; s.mt = mt;
+        s.nch = (fcout + 15) / 16;
+        s.count = (long long)coblks * s.nch * 16 * 4 * mt * 64;
+        a.seg[n++] = s;
+        total += s.count;
+    };
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        addw(k.wdg2[l], b.c2_w, b.cout, b.cout, k.mt2[l], k.cb2[l]);
+        if (k.wdg1[l] >= 0) addw(k.wdg1[l], b.c1_w, b.cin, b.cout, k.mt1[l], k.cb1[l]);
+    }
     {
         PackSeg z{};
         z.kind = 2; z.dst = k.zero; z.count = 64;
@@ -549,6 +572,16 @@ static int conv1x1_or_3x3(const float* zero, const float* in3, int cin3, const f
     return conv_launch(c, mt, st);
 }
 
+static int conv3x3_wino(const float* zero, const float* in3, int cin3, const float* ww, const float* aux, int act,
+                        float* out, int Cout, int mt, int coblks, int B, int H, int W, hipStream_t st) {
+    ConvArgs c{};
+    c.zero = zero;
+    c.in = in3; c.Cin = cin3; c.w3 = ww; c.nch3 = (cin3 + 15) / 16; c.nch1 = 0;
+    c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
+    c.B = B; c.H = H; c.W = W;
+    return conv_wino_launch(c, mt, st);
+}
+
 static int net_backward_impl(const NetPlan& P, const float* params, const float* packed_bwd, const float* x,
                              const float* grad_out, float* grads, float* grad_x, int B, int H, int W,
                              const TrainBufs& tb, hipStream_t st) {
@@ -578,14 +611,20 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
             if (rc) return rc;
         }
         // dU = dgrad_conv2(dO) * GELU'(u)
-        rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU, b.cout,
-                            k.mt2[l], k.cb2[l], B, H, W, st);
+        if (wino_enabled())
+            rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], tb.u[l], 2, dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
+        else
+            rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU,
+                                b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
         if (rc) return rc;
         // conv1 weight grads, dH = dgrad_conv1(dU)
         rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
         if (rc) return rc;
-        rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH, b.cin,
-                            k.mt1[l], k.cb1[l], B, H, W, st);
+        if (wino_enabled() && k.wdg1[l] >= 0)
+            rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], nullptr, 0, dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
+        else
+            rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH,
+                                b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
         if (rc) return rc;
         // depthwise weight/bias grads and the per-sample condition grads
         hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
