@@ -28,13 +28,13 @@ constexpr int WN_KC = 16;                      // input channels per chunk (4 k-
 constexpr int WN_TW = 32;
 constexpr int WN_RS = WN_TW + 2;
 // geometry for NTR tile-rows (2 pixel rows each) per workgroup
-template <int NTR>
+template <int NTR, int CPC = 1>
 struct WinoGeom {
     static constexpr int TH = 2 * NTR;
     static constexpr int HR = TH + 2;
     static constexpr int PLANE = HR * WN_RS;
     static constexpr int PS = (PLANE % 2) ? PLANE : PLANE + 1;   // odd -> conflict-free stride-2 reads across the k lanes
-    static constexpr int IN_LIN = WN_KC * PS;                    // floats per raw-tile buffer
+    static constexpr int IN_LIN = CPC * WN_KC * PS;              // floats per raw-tile buffer (CPC x 16 channels)
     static constexpr int RAW_FLOATS = (2 * IN_LIN + 3) / 4 * 4;  // two buffers
     static constexpr int NTILES = NTR * 16;
     static constexpr int MSTRIDE = NTILES + 1;                   // [xi][co][tiles + 1]
@@ -47,9 +47,10 @@ struct WinoItem {          // one unit of work: an (8|6)x32 pixel tile x one blo
     int b, y0, x0, cb;
 };
 
-template <int MT, int NTR, int ACT>
+template <int MT, int NTR, int ACT, int CPC>
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
-    using WG = WinoGeom<NTR>;
+    using WG = WinoGeom<NTR, CPC>;
+    constexpr int NKS = 4 * CPC;                                   // k-steps (of 4 channels) per chunk
     constexpr int WN_TH = WG::TH, WN_PLANE = WG::PLANE, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
     constexpr int WN_MSTRIDE = WG::MSTRIDE, MPP = WG::MPP;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     const int o00 = lbase + pa0 * WN_RS + pb0, o01 = lbase + pa0 * WN_RS + pb1;
     const int o10 = lbase + pa1 * WN_RS + pb0, o11 = lbase + pa1 * WN_RS + pb1;
 
-    const int nch = p.nch3;                                        // 16-channel chunks
+    const int nch16 = p.nch3;                                      // 16-channel groups of the reduction
+    const int nch = (nch16 + CPC - 1) / CPC;                       // chunks (CPC groups each)
+    const int nks_total = nch16 * 4;
     // raw-tile DMA of chunk c of item `it`.  Wave w stages channel w of the 16-channel chunk: one LDS-DMA wave
     // instruction per tile row (34 active lanes -> 34 consecutive LDS floats).  The buffer descriptor covers exactly
     // that channel plane (0 bytes if the channel does not exist), so everything outside the image -- halo rows and
@@ -101,19 +104,23 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     // carry an offset >= 2^30.  Per instruction: one scalar row offset + one v_add.
     constexpr unsigned OOB = 0x40000000u;
     auto issue = [&](const WinoItem& it, int c, float* buf) {
-        const int ch = c * WN_KC + xi;
-        const float* sbase = p.in + ((size_t)it.b * p.Cin + (ch < p.Cin ? ch : 0)) * HW;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, ch < p.Cin ? HW * 4 : 0, 0x00020000);
-        if (lane < WN_RS) {
-            const int gx = it.x0 + lane - 1;
-            const unsigned loff = (gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
-            float* pl = buf + xi * WN_PS;
+        const int gx = it.x0 + lane - 1;
+        const unsigned loff = (gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
 #pragma unroll
-            for (int r = 0; r < WG::HR; ++r) {
-                const int gy = it.y0 + r - 1;
-                const unsigned roff = (gy >= 0 && gy < H) ? (unsigned)(gy * W) * 4u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(pl + r * WN_RS), 4, (int)(loff + roff), 0, 0, 0);
+        for (int g = 0; g < CPC; ++g) {
+            const int kc = g * 16 + xi;                            // channel of the chunk staged by this wave
+            const int ch = c * (CPC * WN_KC) + kc;
+            const float* sbase = p.in + ((size_t)it.b * p.Cin + (ch < p.Cin ? ch : 0)) * HW;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, ch < p.Cin ? HW * 4 : 0, 0x00020000);
+            if (lane < WN_RS) {
+                float* pl = buf + kc * WN_PS;
+#pragma unroll
+                for (int r = 0; r < WG::HR; ++r) {
+                    const int gy = it.y0 + r - 1;
+                    const unsigned roff = (gy >= 0 && gy < H) ? (unsigned)(gy * W) * 4u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(pl + r * WN_RS), 4, (int)(loff + roff), 0, 0, 0);
+                }
             }
         }
     };
@@ -122,15 +129,16 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     const __amdgpu_buffer_rsrc_t rsw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFFC, 0x00020000);
     const int wlane = lane * 4;
-    constexpr int WCHUNK_B = 16 * 4 * MT * 64 * 4;
     // weight registers: a ring of two k-step slots (MT registers each); slot (ks & 1) holds k-step ks
     float w[2][MT];
     const int abl = p.act >> 8;          // timing ablations (diagnostics only): 1 = no epilogue, 2 = no main loop,
                                          // 4 = weights loaded once (no streaming), 8 = no raw-tile DMA after the first
+    // (chunk c, k-step ks) -> global k-step index; nothing is loaded (or multiplied) past the last real one
     auto load_w = [&](int slot, int cb, int c, int ks) {
         if ((abl & 4) && c > 0) return;
-        const int so = ((cb * nch + c) * 16 + xi) * (4 * MT * 64 * 4) + ks * (MT * 64 * 4);
-        (void)WCHUNK_B;
+        const int gk = c * NKS + ks;
+        if (gk >= nks_total) return;
+        const int so = ((cb * nch16 + (gk >> 2)) * 16 + xi) * (4 * MT * 64 * 4) + (gk & 3) * (MT * 64 * 4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
             w[slot][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsw, wlane, so + mt * 256, 0));
@@ -154,32 +162,31 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
 #pragma unroll
             for (int nt = 0; nt < NTR; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // Schedule inside a chunk.  All 16 waves of the CU meet at the barrier at the end of every chunk, so
-        // nothing young may be in flight there (the barrier carries a vmcnt(0) because of the LDS DMA):
-        //   after k-step 0: load k-step 2 of this chunk          (slot 0)
-        //   after k-step 1: load k-step 3 of this chunk (slot 1); issue the raw-tile DMA of the next chunk
-        //   after k-step 2: load k-step 0 of the next chunk      (slot 0)
-        //   k-step 3, barrier, then load k-step 1 of the next chunk (slot 1) -- needed one k-step later
+        // Schedule inside a chunk of NKS k-steps.  All 16 waves of the CU meet at the barrier at the end of every
+        // chunk, so nothing young may be in flight there (the barrier carries a vmcnt(0) because of the LDS DMA):
+        //   after k-step ks < NKS-2 : load k-step ks+2 of this chunk into the slot just freed
+        //   after k-step 1          : also issue the raw-tile DMA of the next chunk
+        //   after k-step NKS-2      : load k-step 0 of the next chunk
+        //   k-step NKS-1, barrier, then load k-step 1 of the next chunk -- needed one k-step later
         for (int c = 0; c < ((abl & 2) ? 1 : nch); ++c) {
             const float* cur = smem + (c & 1) * WN_IN_LIN;
             const bool more = c + 1 < nch;
             if (c > 0) load_w(1, it.cb, c, 1);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (c * NKS + ks < nks_total) {
 #pragma unroll
-                for (int nt = 0; nt < NTR; ++nt) {
-                    const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
-                    const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
+                    for (int nt = 0; nt < NTR; ++nt) {
+                        const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
+                        const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
+                    }
                 }
-                if (ks == 0) load_w(0, it.cb, c, 2);
-                if (ks == 1) {
-                    load_w(1, it.cb, c, 3);
-                    if (more && !(abl & 8)) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
-                }
-                if (ks == 2 && more) load_w(0, it.cb, c + 1, 0);
+                if (ks < NKS - 2) load_w(ks & 1, it.cb, c, ks + 2);
+                if (ks == 1 && more && !(abl & 8)) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
+                if (ks == NKS - 2 && more) load_w(0, it.cb, c + 1, 0);
             }
             __syncthreads();
         }
@@ -279,29 +286,37 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     }
 }
 
-inline int wino_ntr() {
-    static int v = [] {
-        const char* e = getenv("SINDDM_WINO_NTR");
-        const int n = e ? atoi(e) : 3;
-        return n == 4 ? 4 : 3;
-    }();
+// tile-rows per workgroup: 3 (6x32 pixel tiles).  4 would amortise the weight stream better but needs 20 more
+// accumulator registers than the 128-register budget of a 16-wave workgroup allows (measured: spills, 3x slower).
+inline int wino_ntr() { return 3; }
+
+template <int MT, int NTR, int CPC>
+inline void conv_wino_launch_c(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
+    constexpr size_t lds = WinoGeom<NTR, CPC>::LDS_FLOATS * sizeof(float);
+    switch (a.act & 0xff) {
+        case 1: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 1, CPC>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
+        case 2: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 2, CPC>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
+        default: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 0, CPC>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx);
+    }
+}
+
+// channels per chunk: 16 (measured: 32-channel chunks = half the barriers, but only one M tile per epilogue pass
+// fits in LDS then; 2 % slower end to end).  SINDDM_WINO_CPC=2 selects the 32-channel variant for A/B runs.
+inline int wino_cpc() {
+    static int v = [] { const char* e = getenv("SINDDM_WINO_CPC"); return (e && atoi(e) == 2) ? 2 : 1; }();
     return v;
 }
 
 template <int MT, int NTR>
 inline void conv_wino_launch_a(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
-    constexpr size_t lds = WinoGeom<NTR>::LDS_FLOATS * sizeof(float);
-    switch (a.act & 0xff) {
-        case 1: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 1>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
-        case 2: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 2>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx); break;
-        default: hipLaunchKernelGGL((conv_wino_kernel<MT, NTR, 0>), dim3(grid), dim3(WN_THREADS), lds, st, a, ipx, wpx);
-    }
+    if (wino_cpc() == 2 && a.nch3 >= 2) conv_wino_launch_c<MT, NTR, 2>(a, grid, ipx, wpx, st);
+    else conv_wino_launch_c<MT, NTR, 1>(a, grid, ipx, wpx, st);
 }
 
 template <int MT>
 inline void conv_wino_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, int ntr, hipStream_t st) {
-    if (ntr == 4) conv_wino_launch_a<MT, 4>(a, grid, ipx, wpx, st);
-    else conv_wino_launch_a<MT, 3>(a, grid, ipx, wpx, st);
+    (void)ntr;
+    conv_wino_launch_a<MT, 3>(a, grid, ipx, wpx, st);
 }
 
 inline int device_cu_count() {
