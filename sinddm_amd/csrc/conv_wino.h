@@ -20,6 +20,7 @@
 // caller runs them through the direct kernel first and passes the result as `resid`).
 #pragma once
 #include "conv_mfma.h"
+#include "conv1x1.h"
 
 namespace sinddm {
 

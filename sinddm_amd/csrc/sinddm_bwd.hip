@@ -242,13 +242,17 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
     for (int t = 0; t < tilesX * tilesY; ++t) {
         const int ty = t / tilesX, tx = t - ty * tilesX;
         const int y0 = ty * DWB_TH, x0 = tx * DWB_TW;
-        __syncthreads();
-        for (int i = threadIdx.x; i < DWB_HR * DWB_RS; i += 256) {
+        // issue every global load of this tile (halo tile of x + this thread's 4 dh values) before the first wait
+        constexpr int DWB_LD = (DWB_HR * DWB_RS + 255) / 256;
+        float stg[DWB_LD];
+#pragma unroll
+        for (int k = 0; k < DWB_LD; ++k) {
+            const int i = threadIdx.x + k * 256;
             const int rr = i / DWB_RS, cc = i - rr * DWB_RS;
             const int gy = y0 + rr - 2, gx = x0 + cc - 2;
-            tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xs[(size_t)gy * W + gx] : 0.0f;
+            const bool ok = i < DWB_HR * DWB_RS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            stg[k] = ok ? xs[(size_t)gy * W + gx] : 0.0f;
         }
-        __syncthreads();
         const int gx = x0 + ln;
         float d[4];
 #pragma unroll
@@ -256,6 +260,13 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
             const int gy = y0 + wv * 4 + i;
             d[i] = (gy < H && gx < W) ? ds[(size_t)gy * W + gx] : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DWB_LD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < DWB_HR * DWB_RS) tile[i] = stg[k];
+        }
+        __syncthreads();
         acc[25] += (d[0] + d[1]) + (d[2] + d[3]);
 #pragma unroll
         for (int dy = 0; dy < 8; ++dy) {
@@ -569,6 +580,7 @@ static int conv1x1_or_3x3(const float* zero, const float* in3, int cin3, const f
     c.in2 = in1; c.Cin2 = cin1; c.w1 = w1; c.nch1 = nch1;
     c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
     c.B = B; c.H = H; c.W = W;
+    if (nch3 == 0) return conv1x1_launch(c, mt, st);       // pure channel mixing: the HBM-bound 1x1 kernel
     return conv_launch(c, mt, st);
 }
 

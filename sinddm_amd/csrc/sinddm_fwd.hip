@@ -245,17 +245,29 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     const int y0 = ty * DW_TH, xg0 = gxi * (DW_NX * DW_TW);
     const size_t plane = ((size_t)b * C + c) * H * W;
     const float* src = x + plane;
+    // stage all DW_NX halo tiles: every load is issued before the first LDS write (the loads are independent;
+    // a rolled loop would wait for each one in turn and make the kernel latency-bound)
+    constexpr int DW_LD = (DW_HR * DW_RS + 255) / 256;
+    float stg[DW_NX][DW_LD];
 #pragma unroll
     for (int t = 0; t < DW_NX; ++t) {
         const int x0 = xg0 + t * DW_TW;
-        if (x0 < W) {
-            for (int i = threadIdx.x; i < DW_HR * DW_RS; i += 256) {
-                const int r = i / DW_RS, cc = i - r * DW_RS;
-                const int gy = y0 + r - 2, gx = x0 + cc - 2;
-                tile[t][i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? src[(size_t)gy * W + gx] : 0.0f;
-            }
+#pragma unroll
+        for (int k = 0; k < DW_LD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int r = i / DW_RS, cc = i - r * DW_RS;
+            const int gy = y0 + r - 2, gx = x0 + cc - 2;
+            const bool ok = i < DW_HR * DW_RS && x0 < W && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            stg[t][k] = ok ? src[(size_t)gy * W + gx] : 0.0f;
         }
     }
+#pragma unroll
+    for (int t = 0; t < DW_NX; ++t)
+#pragma unroll
+        for (int k = 0; k < DW_LD; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < DW_HR * DW_RS) tile[t][i] = stg[t][k];
+        }
     float wk[25];
 #pragma unroll
     for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + (flip ? 24 - k : k)];   // flip -> transposed conv (data grad)
@@ -483,7 +495,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
                 r1.in2 = cur; r1.Cin2 = b.cin; r1.w1 = packed + b.pk_res; r1.nch1 = b.nchr; r1.nch3 = 0;
                 r1.bias = packed + b.pk_b2; r1.out = obuf; r1.Cout = b.cout; r1.coblks = b.coblks;
                 r1.B = B; r1.H = H; r1.W = W; r1.zero = packed + P.pk_zero;
-                rc = conv_launch(r1, b.mt, st);
+                rc = conv1x1_launch(r1, b.mt, st);
                 if (rc) return rc;
                 c2.resid = obuf; c2.bias = nullptr;          // in place: each thread reads resid[o] before writing out[o]
             } else {
