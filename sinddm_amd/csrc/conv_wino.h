@@ -173,13 +173,27 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
             const float* cur = smem + (c & 1) * WN_IN_LIN;
             const bool more = c + 1 < nch;
             if (c > 0) load_w(1, it.cb, c, 1);
+            // the four raw values of the next (k-step, tile-row) group are fetched from LDS before the MFMAs of
+            // the current group are issued, so the LDS round trip hides under those MFMAs
+            float r4[4];
+            {
+                const float* q = cur;
+                r4[0] = q[o00]; r4[1] = q[o01]; r4[2] = q[o10]; r4[3] = q[o11];
+            }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                if (c * NKS + ks < nks_total) {
+                const bool live = (CPC == 1) || (c * NKS + ks < nks_total);
 #pragma unroll
-                    for (int nt = 0; nt < NTR; ++nt) {
-                        const float* q = cur + ks * 4 * WN_PS + nt * 2 * WN_RS;
-                        const float bv = s00 * q[o00] + s01 * q[o01] + s10 * q[o10] + s11 * q[o11];
+                for (int nt = 0; nt < NTR; ++nt) {
+                    const float bv = s00 * r4[0] + s01 * r4[1] + s10 * r4[2] + s11 * r4[3];
+                    // next group (same k-step next tile-row, or first tile-row of the next k-step)
+                    if (nt + 1 < NTR || ks + 1 < NKS) {
+                        const int nks = (nt + 1 < NTR) ? ks : ks + 1;
+                        const int nnt = (nt + 1 < NTR) ? nt + 1 : 0;
+                        const float* q = cur + nks * 4 * WN_PS + nnt * 2 * WN_RS;
+                        r4[0] = q[o00]; r4[1] = q[o01]; r4[2] = q[o10]; r4[3] = q[o11];
+                    }
+                    if (live) {
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
