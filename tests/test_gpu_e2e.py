@@ -1,0 +1,100 @@
+"""GPU end-to-end tests through the reference-shaped public API: MultiscaleTrainer.sample_scales (incl. --scale_mul
+retargeting and size extrapolation), checkpoint save/load, and train() -> sample() on a tiny configuration."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import rel_l2
+from oracle import sinddm_oracle as O
+from sinddm_amd.synth import closed_form_state_dict, hash_randn, noise_key
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _trainer(golden, tmp_path, dim=32, T=20, batch=2, **kw):
+    from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
+    from sinddm_amd.trainer import MultiscaleTrainer
+    meta = golden("g11_img_scales.json")["C1"]
+    pyr = golden("c1_pyramid.npz")
+    folder = str(tmp_path / "balloons") + "/"
+    for key in pyr.files:
+        os.makedirs(folder + key, exist_ok=True)
+        Image.fromarray(pyr[key]).save(folder + key + "/balloons.png")
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    sizes = [tuple(s) for s in meta["sizes"]]
+    d = MultiScaleGaussianDiffusion(net, n_scales=meta["n_scales"], scale_factor=meta["scale_factor"], image_sizes=sizes,
+                                    timesteps=T, train_full_t=True, scale_losses=meta["rescale_losses"], loss_factor=1,
+                                    loss_type="l1", device=DEV, reblurring=True, omega=0,
+                                    results_folder=str(tmp_path / "res")).to(DEV)
+    tr = MultiscaleTrainer(d, folder=folder, n_scales=meta["n_scales"], scale_factor=meta["scale_factor"],
+                           image_sizes=sizes, train_batch_size=batch, train_lr=1e-3, train_num_steps=6,
+                           gradient_accumulate_every=1, step_start_ema=2, update_ema_every=2,
+                           save_and_sample_every=10 ** 9, avg_window=2, sched_milestones=[3],
+                           results_folder=str(tmp_path / "res"), device=DEV, **kw)
+    return tr, meta
+
+
+def test_sample_scales_matches_oracle_chain(golden, tmp_path):
+    """sample_scales (the main.py --mode sample path) == the oracle's chain with the same hash noise, T=20."""
+    tr, meta = _trainer(golden, tmp_path)
+    d = tr.ema_model
+    d.noise_fn = lambda kind, shape, s, t, dev: hash_randn(shape, noise_key(kind, s, t)).to(dev)
+    outs = tr.sample_scales(scale_mul=(1, 1), custom_sample=True, batch_size=2, custom_t_list=d.num_timesteps_ideal[1:],
+                            desc="t", save_unbatched=True)
+    assert len(outs) == meta["n_scales"]
+    sched = O.make_schedule(20, meta["n_scales"], meta["rescale_losses"], 1, train_full_t=True)
+    sizes = [tuple(s) for s in meta["image_sizes_hw"]]
+
+    class Noise(dict):
+        def __missing__(self, k):
+            kind, s = k[0], k[1]
+            t = k[2] if len(k) > 2 else 0
+            return hash_randn((2, 3) + sizes[s], noise_key(kind, s, t))
+
+    with torch.no_grad():
+        ref = O.sample_chain(sched, closed_form_state_dict(32), sizes, Noise(), 2)
+    for i, (a, b) in enumerate(zip(outs, ref)):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert rel_l2(a.cpu(), b) < 1e-4, i
+    pngs = [f for _, _, fs in os.walk(tmp_path / "res") for f in fs if f.endswith(".png")]
+    assert len(pngs) >= meta["n_scales"] + 2          # per-scale grids + unbatched finals
+
+
+def test_scale_mul_and_extrapolated_sizes(golden, tmp_path):
+    tr, meta = _trainer(golden, tmp_path, T=4)
+    outs = tr.sample_scales(scale_mul=(2, 1.5), custom_sample=True, batch_size=1, desc="m", save_unbatched=False,
+                            save_images=False)
+    for i, o in enumerate(outs):
+        h, w = meta["image_sizes_hw"][i]
+        assert tuple(o.shape) == (1, 3, int(h * 2), int(w * 1.5))
+        assert torch.isfinite(o).all()
+    d = tr.ema_model
+    big = d.sample_via_scale(1, outs[-1], s=2, scale_mul=(1, 1), custom_sample=True, custom_img_size_idx=3, custom_t=2)
+    assert tuple(big.shape[2:]) == d.target_size(2, (1, 1), True, 3)      # extrapolated size (models.py:555-558)
+
+
+def test_train_then_checkpoint_roundtrip(golden, tmp_path):
+    tr, meta = _trainer(golden, tmp_path, T=20)
+    torch.manual_seed(0)
+    tr.train()
+    assert tr.step == 6 and len(tr.running_loss) >= 1
+    p_before = tr.model.denoise_fn.flat_params.clone()
+    e_before = tr.ema_model.denoise_fn.flat_params.clone()
+    assert not torch.equal(p_before, e_before)            # EMA lags the model after step_start_ema
+    tr.save(1)
+    ck = torch.load(str(tmp_path / "res" / "model-1.pt"), weights_only=False)
+    assert set(ck.keys()) >= {"step", "model", "ema", "sched", "running_loss", "running_scale"}
+    assert "denoise_fn.l3.net.2.weight" in ck["model"] and "gammas" in ck["model"]
+    tr2, _ = _trainer(golden, tmp_path, T=20)
+    tr2.load(1)
+    assert tr2.step == 6
+    assert torch.equal(tr2.model.denoise_fn.flat_params, p_before)
+    assert torch.equal(tr2.ema_model.denoise_fn.flat_params, e_before)
+    # the loaded EMA model samples (packed weights are rebuilt from the loaded parameters)
+    x = tr2.ema_model.sample(batch_size=1)
+    assert torch.isfinite(x).all()
