@@ -121,7 +121,7 @@ def main():
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("conv_mfma_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("conv_bytes_per_launch")   # PMC passes, profiles/r01f_pmc_summary.txt
         except Exception:
             traffic = None
     wino = os.environ.get("SINDDM_CONV_WINO", "1") != "0"

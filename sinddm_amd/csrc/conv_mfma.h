@@ -9,7 +9,7 @@
 // wave owns MT x NT accumulator tiles (MT*16 channels x NT*16 pixels).  K is walked in chunks of
 // KC=8 input channels: the chunk's weights ([tap][ci][co], pre-packed so the copy is linear
 // float4) and the chunk's input halo tile ((TH+2) x 34 per channel) are staged in LDS; the loads of
-// chunk c+1 are issued into registers before the MFMAs of chunk c so their latency hides under
+// chunk c+1 are issued (LDS DMA, double buffered) before the MFMAs of chunk c so their latency hides under
 // compute.  LDS strides are chosen == 16 (mod 32) so both operand reads are bank-conflict-free.
 // Inside a chunk the A/B fragments of k-step i+1 are read from LDS before the MFMAs of k-step i
 // (register double buffering), so the matrix pipe never waits on an LDS round trip.
@@ -129,178 +129,9 @@ __device__ __forceinline__ void conv_compute_chunk(f32x4 (&acc)[MT][NT], const f
     }
 }
 
-template <int MT, int NT, int VAR>
-__global__ __launch_bounds__(CONV_THREADS) void conv_mfma_kernel(ConvArgs p) {
-    using Cfg = ConvCfg<MT, NT>;
-    using G = ConvGeom<NT>;
-    constexpr int CO_LDS = Cfg::CO_LDS;
-    constexpr int WREGS = Cfg::WREGS;
-    constexpr int IREGS = G::IREGS;
-    constexpr int PLANE = G::HR * G::RS;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW = smem;
-    float* sIn = smem + 9 * KC * CO_LDS;
-
-    // XCD-aware decode: each XCD (private L2) gets a contiguous range of tiles; the co-blocks of
-    // one tile run back to back on the same XCD so the input tile is served from that L2.
-    const int id = blockIdx.x;
-    const int xcd = id & 7;
-    const int slot = id >> 3;
-    const int cb = slot % p.coblks;
-    const int tl = slot / p.coblks;
-    const int tile = xcd * p.tiles_per_xcd + tl;
-    if (tile >= p.ntiles) return;
-    const int tpi = p.tilesX * p.tilesY;
-    const int b = tile / tpi;
-    const int tr = tile - b * tpi;
-    const int ty = tr / p.tilesX;
-    const int tx = tr - ty * p.tilesX;
-    const int y0 = ty * G::TH, x0 = tx * G::TW;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int l16 = lane & 15, kq = lane >> 4;
-    const int H = p.H, W = p.W;
-    const int HW = H * W;
-
-    // ---- per-thread staging map (same for every chunk) ----
-    int goff[IREGS];
-#pragma unroll
-    for (int i = 0; i < IREGS; ++i) {
-        const int idx = tid + i * CONV_THREADS;
-        const int kc = idx / PLANE;
-        const int e = idx - kc * PLANE;
-        const int r = e / G::RS;
-        const int c = e - r * G::RS;
-        const int gy = y0 + r - 1, gx = x0 + c - 1;
-        const bool ok = idx < G::IN_ELEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        goff[i] = ok ? kc * HW + gy * W + gx : -1;
-    }
-
-    float4 wreg[WREGS];
-    float ireg[IREGS];
-
-    const int nch = p.nch3 + p.nch1;
-    auto load_chunk = [&](int c) {
-        const bool is3 = c < p.nch3;
-        const int cc = is3 ? c : c - p.nch3;
-        const float* src = is3 ? p.in : p.in2;
-        const int C = is3 ? p.Cin : p.Cin2;
-        const int ch0 = cc * KC;
-        const float* sbase = src + ((size_t)b * C + ch0) * HW;
-        const int nvalid = C - ch0;  // channels of this chunk that exist
-#pragma unroll
-        for (int i = 0; i < IREGS; ++i) {
-            const int idx = tid + i * CONV_THREADS;
-            const int kc = idx / PLANE;
-            ireg[i] = (goff[i] >= 0 && kc < nvalid) ? sbase[goff[i]] : 0.0f;
-        }
-        const float4* wsrc;
-        int n4;
-        if (is3) {
-            wsrc = reinterpret_cast<const float4*>(p.w3) + ((size_t)cb * p.nch3 + cc) * Cfg::W3_F4;
-            n4 = Cfg::W3_F4;
-        } else {
-            wsrc = reinterpret_cast<const float4*>(p.w1) + ((size_t)cb * p.nch1 + cc) * Cfg::W1_F4;
-            n4 = Cfg::W1_F4;
-        }
-#pragma unroll
-        for (int j = 0; j < WREGS; ++j) {
-            const int i4 = tid + j * CONV_THREADS;
-            if (i4 < n4) wreg[j] = wsrc[i4];
-        }
-    };
-    auto store_chunk = [&](int c) {
-        const int n4 = (c < p.nch3) ? Cfg::W3_F4 : Cfg::W1_F4;
-#pragma unroll
-        for (int j = 0; j < WREGS; ++j) {
-            const int i4 = tid + j * CONV_THREADS;
-            if (i4 < n4) reinterpret_cast<float4*>(sW)[i4] = wreg[j];
-        }
-#pragma unroll
-        for (int i = 0; i < IREGS; ++i) {
-            const int idx = tid + i * CONV_THREADS;
-            if (idx < G::IN_ELEMS) {
-                const int kc = idx / PLANE;
-                const int e = idx - kc * PLANE;
-                sIn[kc * G::PS + e] = ireg[i];
-            }
-        }
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int aBase = kq * CO_LDS + l16;
-    const int bBase = kq * G::PS + (wave * G::RPW) * G::RS + l16;
-
-    // VAR 2 / 3 are timing ablations only (wrong results): 2 = MFMA loop without the per-chunk
-    // staging, 3 = staging without the MFMA loop.
-    load_chunk(0);
-    for (int c = 0; c < nch; ++c) {
-        if ((VAR != 2 && VAR != 6 && VAR != 7) || c == 0) {
-            __syncthreads();            // every wave finished reading the previous chunk
-            store_chunk(c);
-            __syncthreads();
-            if (c + 1 < nch) load_chunk(c + 1);   // in flight during the MFMAs below
-        }
-        if (VAR == 3) {
-            acc[0][0][0] += sW[aBase] * sIn[bBase];
-            continue;
-        }
-        if (VAR == 7) {
-            // MFMA issue-rate ablation: operands stay in registers, no LDS traffic in the loop
-            Frag<MT, NT> f;
-            conv_load_frag<MT, NT, 9>(f, sW, sIn, aBase, bBase, 0);
-#pragma unroll
-            for (int st = 0; st < 9 * (KC / 4); ++st) {
-                conv_mfma_frag<MT, NT>(acc, f);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            continue;
-        }
-        if (c < p.nch3)
-            conv_compute_chunk<MT, NT, 9, ((VAR == 1 || VAR == 6) ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
-        else
-            conv_compute_chunk<MT, NT, 1, ((VAR == 1 || VAR == 6) ? 1 : 0)>(acc, sW, sIn, aBase, bBase);
-    }
-
-    // ---- epilogue: bias, activation, residual, store (C/D layout: col = lane&15 -> pixel,
-    //      row = (lane>>4)*4 + r -> output channel) ----
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int col = mt * 16 + kq * 4 + r;
-            const int co = cb * (MT * 16) + col;
-            if (co >= p.Cout) continue;
-            const float bv = p.bias ? p.bias[cb * (MT * 16) + col] : 0.0f;
-            const size_t cbase = ((size_t)b * p.Cout + co) * HW;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int y = y0 + wave * G::RPW + nt / G::TPR;
-                const int x = x0 + (nt % G::TPR) * 16 + l16;
-                if (y < H && x < W) {
-                    const size_t o = cbase + (size_t)y * W + x;
-                    float v = acc[mt][nt][r] + bv;
-                    if (p.out_pre) p.out_pre[o] = v;
-                    if (p.act == 1) v = gelu_erf(v);
-                    else if (p.act == 2) v *= gelu_erf_grad(p.aux[o]);
-                    if (p.resid) v += p.resid[o];
-                    p.out[o] = v;
-                }
-            }
-        }
-    }
-}
-
 // =====================================================================================
-// LDS-DMA variant: both operands go global -> LDS with global_load_lds (no VGPR round trip, no
-// ds_write pass), LDS is double buffered and there is ONE barrier per K chunk:
+// Both operands go global -> LDS with global_load_lds (no VGPR round trip, no ds_write pass), LDS is
+// double buffered and there is ONE barrier per K chunk:
 //     issue DMA(chunk c+1 -> buf[(c+1)&1]) ; MFMAs(chunk c from buf[c&1]) ; vmcnt(0) ; barrier
 // The DMA destination is lane-linear (wave-uniform base + lane*size), so the LDS images are walked
 // linearly (including the pad floats of every plane); halo / out-of-image / missing-channel
@@ -458,24 +289,15 @@ struct ConvProfiler {
 };
 ConvProfiler& conv_profiler();
 
-// tuning knobs (read once): SINDDM_CONV_NT in {2,4}, SINDDM_CONV_VAR in {0,1}
-struct ConvTuning {
-    int nt, var;
-};
-inline ConvTuning conv_tuning() {
-    static ConvTuning t = [] {
-        ConvTuning r{0, -1};   // nt 0 / var -1 = pick per launch
-        if (const char* e = getenv("SINDDM_CONV_NT")) r.nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 0);
-        if (const char* e = getenv("SINDDM_CONV_VAR")) r.var = atoi(e) % 10;   // A/B + ablation knob
-        return r;
+// tuning knob (read once): SINDDM_CONV_VAR = 4 forces 4-wave workgroups on 4x32 tiles, 8 forces 8-wave
+// workgroups on 8x32 tiles; default (-1) picks per launch
+inline int conv_tuning_var() {
+    static int v = [] {
+        const char* e = getenv("SINDDM_CONV_VAR");
+        const int x = e ? atoi(e) : -1;
+        return (x == 4 || x == 8) ? x : -1;
     }();
-    return t;
-}
-
-template <int MT, int NT, int VAR>
-inline void conv_launch_t(const ConvArgs& a, unsigned grid, hipStream_t st) {
-    constexpr size_t lds = ConvCfg<MT, NT>::LDS_FLOATS * sizeof(float);
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, VAR>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+    return v;
 }
 
 template <int MT, int NT, int PIN, int WV>
@@ -485,56 +307,21 @@ inline void conv_launch_dma_t(const ConvArgs& a, unsigned grid, hipStream_t st) 
 }
 
 template <int MT>
-inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int nt, int var, hipStream_t st) {
-    if (var == 6 || var == 7) {
-        if (nt == 4) { if (var == 6) conv_launch_t<MT, 4, 6>(a, grid, st); else conv_launch_t<MT, 4, 7>(a, grid, st); }
-        else         { if (var == 6) conv_launch_t<MT, 2, 6>(a, grid, st); else conv_launch_t<MT, 2, 7>(a, grid, st); }
-        return;
-    }
-    if (var == 8) {   // 8 waves x (MT x 2) tiles: 8x32 pixel tile, 4 waves/SIMD at 2 workgroups/CU
-        conv_launch_dma_t<MT, 2, 0, 8>(a, grid, st);
-        return;
-    }
-    if (var == 9) {   // 16 waves: 16x32 pixel tile, one workgroup per CU
-        conv_launch_dma_t<MT, 2, 0, 16>(a, grid, st);
-        return;
-    }
-    if (var >= 4) {
-        if (nt == 4) { if (var == 5) conv_launch_dma_t<MT, 4, 1, 4>(a, grid, st); else conv_launch_dma_t<MT, 4, 0, 4>(a, grid, st); }
-        else         { if (var == 5) conv_launch_dma_t<MT, 2, 1, 4>(a, grid, st); else conv_launch_dma_t<MT, 2, 0, 4>(a, grid, st); }
-        return;
-    }
-    if (nt == 4) {
-        switch (var) {
-            case 1: conv_launch_t<MT, 4, 1>(a, grid, st); break;
-            case 2: conv_launch_t<MT, 4, 2>(a, grid, st); break;
-            case 3: conv_launch_t<MT, 4, 3>(a, grid, st); break;
-            default: conv_launch_t<MT, 4, 0>(a, grid, st);
-        }
-    } else {
-        switch (var) {
-            case 1: conv_launch_t<MT, 2, 1>(a, grid, st); break;
-            case 2: conv_launch_t<MT, 2, 2>(a, grid, st); break;
-            case 3: conv_launch_t<MT, 2, 3>(a, grid, st); break;
-            default: conv_launch_t<MT, 2, 0>(a, grid, st);
-        }
-    }
+inline void conv_launch_mt(const ConvArgs& a, unsigned grid, int var, hipStream_t st) {
+    if (var == 8) conv_launch_dma_t<MT, 2, 0, 8>(a, grid, st);   // 8 waves x (MT x 2) tiles: 8x32 pixel tile
+    else conv_launch_dma_t<MT, 2, 0, 4>(a, grid, st);            // 4 waves x (MT x 2) tiles: 4x32 pixel tile
 }
 
 inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     ConvArgs a = a_in;
-    ConvTuning tune = conv_tuning();
-    const long long blocks8 = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.coblks;
-    if (tune.var < 0) {
-        // default: 8-wave workgroups on 8x32 pixel tiles (4 waves/SIMD at 2 workgroups per CU); when
-        // that would leave CUs without two workgroups (coarse pyramid scales, tiny batches) use 4-wave
-        // workgroups on 4x32 tiles instead
-        tune.var = blocks8 >= 512 ? 8 : 4;
-        if (tune.var == 4 && tune.nt == 0) tune.nt = 2;
+    int var = conv_tuning_var();
+    if (var < 0) {
+        // default: 8-wave workgroups on 8x32 pixel tiles (4 waves/SIMD at 2 workgroups per CU); when that would
+        // leave CUs without two workgroups (coarse pyramid scales, tiny batches) 4-wave workgroups on 4x32 tiles
+        const long long blocks8 = (long long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8) * a.coblks;
+        var = blocks8 >= 512 ? 8 : 4;
     }
-    if (tune.nt == 0) tune.nt = blocks8 >= 1024 ? 4 : 2;
-    const int TH = tune.var == 9 ? ConvGeom<2, 16>::TH
-                 : (tune.var == 8 ? ConvGeom<2, 8>::TH : (tune.nt == 4 ? ConvGeom<4>::TH : ConvGeom<2>::TH));
+    const int TH = var == 8 ? ConvGeom<2, 8>::TH : ConvGeom<2, 4>::TH;
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
     if (rec) {
@@ -551,9 +338,9 @@ inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     const unsigned grid = (unsigned)(a.tiles_per_xcd * 8 * a.coblks);
     switch (mt) {
-        case 5: conv_launch_mt<5>(a, grid, tune.nt, tune.var, st); break;
-        case 2: conv_launch_mt<2>(a, grid, tune.nt, tune.var, st); break;
-        case 1: conv_launch_mt<1>(a, grid, tune.nt, tune.var, st); break;
+        case 5: conv_launch_mt<5>(a, grid, var, st); break;
+        case 2: conv_launch_mt<2>(a, grid, var, st); break;
+        case 1: conv_launch_mt<1>(a, grid, var, st); break;
         default: return SINDDM_E_BADSHAPE;
     }
     if (rec) {

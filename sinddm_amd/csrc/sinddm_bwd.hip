@@ -60,8 +60,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
     const int l16 = lane & 15, kq = lane >> 4;
     const int H = p.H, W = p.W, HW = H * W;
     const int tpi = p.tilesX * p.tilesY;
-    const float* zsrc = p.zero + lane;
-
+    // LDS-DMA of one pixel tile with buffer descriptors: the bounds check zero-fills everything outside the image or
+    // the channel range (those lanes / rows carry an offset >= 2^30), so an instruction costs one v_add.
+    constexpr unsigned OOB = 0x40000000u;
     auto issue = [&](int tile, float* buf) {
         const int b = tile / tpi;
         const int tr = tile - b * tpi;
@@ -70,22 +71,23 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
         // dout tile: one wave instruction per channel row of 64 pixels (lane -> (row, col))
         {
             const int r = lane >> 5, c = lane & 31;
-            const bool ok = (y0 + r < H) && (x0 + c < W);
-            const int off = (y0 + r) * W + x0 + c;
-            const float* base = p.dout + (size_t)b * p.Cout * HW;
+            const unsigned loff = ((y0 + r < H) && (x0 + c < W)) ? (unsigned)((y0 + r) * W + x0 + c) * 4u : OOB;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.dout + (size_t)b * p.Cout * HW), 0, p.Cout * HW * 4, 0x00020000);
 #pragma unroll 4
             for (int k = 0; k < MT * 4; ++k) {
                 const int col = wave + 4 * k;
                 const int co = cb * MT * 16 + col;
-                const float* g = (ok && co < p.Cout) ? base + (size_t)co * HW + off : zsrc;
-                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(buf + col * WG_PSO), 4, 0, 0);
+                const unsigned coff = co < p.Cout ? (unsigned)(co * HW) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(buf + col * WG_PSO), 4, (int)(loff + coff), 0, 0, 0);
             }
         }
         // input tile with 1-pixel halo: one wave instruction per (channel, row), 34 active lanes
         if (lane < WG_IRS) {
             const int gx = x0 + lane - 1;
-            const bool okx = gx >= 0 && gx < W;
-            const float* base = p.in + (size_t)b * p.Cin * HW;
+            const unsigned loff = (gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.in + (size_t)b * p.Cin * HW), 0, p.Cin * HW * 4, 0x00020000);
             float* ibuf = buf + MT * 16 * WG_PSO;
 #pragma unroll 4
             for (int k = 0; k < WG_CI * WG_IHR / 4; ++k) {
@@ -93,9 +95,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
                 const int cil = qi / WG_IHR, r = qi - cil * WG_IHR;
                 const int ci = cib * WG_CI + cil;
                 const int gy = y0 + r - 1;
-                const bool ok = okx && ci < p.Cin && gy >= 0 && gy < H;
-                const float* g = ok ? base + (size_t)ci * HW + (size_t)gy * W + gx : zsrc;
-                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ibuf + cil * WG_PSI + r * WG_IRS), 4, 0, 0);
+                const unsigned roff = (ci < p.Cin && gy >= 0 && gy < H) ? (unsigned)(ci * HW + gy * W) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(ibuf + cil * WG_PSI + r * WG_IRS), 4, (int)(loff + roff), 0, 0, 0);
             }
         }
     };
