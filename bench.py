@@ -169,10 +169,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import sinddm_oracle as O
         from sinddm_amd.synth import closed_form_state_dict
-        cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
+        ncpu = os.cpu_count() or 1
         sd = closed_form_state_dict(160)
         sched = O.make_schedule(cfg["T"], n_scales, cfg["rescale_losses"], 1, train_full_t=True)
+        # pick the thread count that is actually fastest for this op mix (oneDNN convs stop scaling long before
+        # 256 threads): a short calibration on a small image, then the measurement with the winner
+        cands = sorted({ncpu, min(ncpu, 64), min(ncpu, 32)})
+        best, cores = None, ncpu
+        xs = torch.randn(1, 3, 94, 126)
+        for nthr in cands:
+            torch.set_num_threads(nthr)
+            with torch.no_grad():
+                O.net_forward(sd, xs, torch.tensor([5]), 2)
+                t0 = time.perf_counter()
+                O.net_forward(sd, xs, torch.tensor([5]), 2)
+                dtc = time.perf_counter() - t0
+            if best is None or dtc < best:
+                best, cores = dtc, nthr
+        torch.set_num_threads(cores)
         cb = min(B, 4)
         xc = torch.randn(cb, 3, H, W)
         xt = torch.randn(cb, 3, H, W)

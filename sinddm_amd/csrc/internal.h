@@ -34,6 +34,7 @@ struct TrainBufs {
     float* s[4];    // backward scratch, dim channels each
     float* dcond;   // [B][cond_stride]
     float* small;   // cond-path backward scratch  [B][4*32 + 32 + 128]
+    float* wscr;    // [dim][9][dim] staging slab of the 3x3 weight-gradient kernel
 };
 
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,

@@ -39,6 +39,8 @@ struct WgradArgs {
     int B, H, W, Cin, Cout;
     int coblks, ciblks, S;
     int tilesX, tilesY, ntiles;
+    int abl;             // ablation bits (tuning only): 1 = skip the steady-state DMA, 2 = skip the epilogue
+    int scr;             // 1: gw is a [co][tap][ci] staging slab (wgrad3x3_kernel only)
 };
 
 template <int MT, int TAPS>
@@ -181,6 +183,199 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
     }
 }
 
+// -------------------------------------------------------------------------------------
+// 3x3 weight gradient for Cout % 80 == 0: one 15-wave workgroup per CU owns an 80(co) x 80(ci) x 9 slab.
+// Wave (tap-row, ci-tile) accumulates 5 co-tiles x 3 taps (60 registers) over every pixel of the tile, so no
+// cross-wave reduction is needed and a 64-pixel tile (73 KB of LDS) feeds 3600 MFMAs: 2.4x fewer L2->LDS bytes
+// per FLOP than the K-split kernel above, whose DMA latency cost 38% of its time (ablation in DESIGN.md).
+// -------------------------------------------------------------------------------------
+constexpr int W3_WAVES = 16;                              // 15 compute waves + 1 that only moves data (4 waves per SIMD)
+constexpr int W3_THREADS = W3_WAVES * 64;
+constexpr int W3_C = 80;                                  // co and ci per workgroup
+constexpr int W3_BUF = W3_C * WG_PSO + W3_C * WG_PSI;     // floats per stage
+
+__global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(WgradArgs p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int pairs = p.coblks * p.ciblks;
+    const int q = slot % pairs;
+    const int s = (slot / pairs) * 8 + xcd;          // pixel-split index; same-split slabs share an XCD/L2
+    const int cb = q / p.ciblks, cib = q - cb * p.ciblks;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int trw = wave / 5, cit = wave - trw * 5;  // tap row, ci tile of this wave
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int tpi = p.tilesX * p.tilesY;
+    const int ci0 = cib * W3_C;
+    const int nci = min(W3_C, p.Cin - ci0);
+
+    // LDS-DMA of one pixel tile, cut into 5 uniform per-wave "groups" (1 dout row + 4 input rows, one wave
+    // instruction each) so the main loop can spread them between its MFMA groups: 16 waves issuing 25 loads back
+    // to back after the barrier stalled the matrix pipe for ~20% of a tile.  Buffer bounds checking zero-fills
+    // halo / channel padding (offset >= 2^30).  16 waves x 5 = 80 dout rows, 16 x 20 = 320 (channel, row) pairs.
+    constexpr unsigned OOB = 0x40000000u;
+    constexpr int NG = 5;
+    static_assert(W3_WAVES * NG == W3_C && W3_WAVES * NG * 4 == W3_C * WG_IHR, "slot split");
+    struct TileAddr {
+        __amdgpu_buffer_rsrc_t rd, ri;
+        unsigned loff_d, loff_i;
+        int gyW;        // (gy * W) of this wave's input row, or -1 if the row is outside the image
+    };
+    const int irow = wave & 3;          // input-tile row this wave loads (of 4), channels (wave>>2) + 4*k
+    auto tile_addr = [&](int tile) {
+        TileAddr ta;
+        const int b = tile / tpi;
+        const int tr = tile - b * tpi;
+        const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+        const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+        const int r = lane >> 5, c = lane & 31;
+        ta.loff_d = ((y0 + r < H) && (x0 + c < W)) ? (unsigned)((y0 + r) * W + x0 + c) * 4u : OOB;
+        const int gx = x0 + lane - 1;
+        ta.loff_i = (gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
+        ta.rd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dout + ((size_t)b * p.Cout + (size_t)cb * W3_C) * HW), 0, W3_C * HW * 4, 0x00020000);
+        ta.ri = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in + ((size_t)b * p.Cin + ci0) * HW), 0, nci * HW * 4, 0x00020000);
+        const int gy = y0 + irow - 1;
+        ta.gyW = (gy >= 0 && gy < H) ? gy * W : -1;
+        return ta;
+    };
+    auto issue_group = [&](const TileAddr& ta, float* buf, int g) {
+        {   // dout: one instruction per channel row of 64 pixels (lane -> (row, col))
+            const int col = wave + W3_WAVES * g;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ta.rd, (lds_ptr)(buf + col * WG_PSO), 4,
+                                                     (int)(ta.loff_d + (unsigned)(col * HW) * 4u), 0, 0, 0);
+        }
+        if (lane < WG_IRS) {   // input with 1-pixel halo: one instruction per (channel, row), 34 lanes
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cil = (wave >> 2) + 16 * g + 4 * i;
+                const unsigned roff = (cil < nci && ta.gyW >= 0) ? (unsigned)(cil * HW + ta.gyW) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    ta.ri, (lds_ptr)(buf + W3_C * WG_PSO + cil * WG_PSI + irow * WG_IRS), 4, (int)(ta.loff_i + roff), 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const bool active = wave < 15 && ci0 + cit * 16 < p.Cin;   // wave-uniform; idle waves still move data
+    const bool dobias = p.gb != nullptr && cib == 0 && wave == 15;   // the data-moving wave also sums dout for the bias
+    const int aBase = l16 * WG_PSO + kq;
+    const int bBase = W3_C * WG_PSO + (cit * 16 + l16) * WG_PSI + trw * WG_IRS + kq;
+
+    int it = 0;
+    if (s < p.ntiles) {
+        const TileAddr ta = tile_addr(s);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) issue_group(ta, smem, g);
+    }
+    for (int tile = s; tile < p.ntiles; tile += p.S, ++it) {
+        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+        const float* cur = smem + (it & 1) * W3_BUF;
+        float* nxt = smem + ((it + 1) & 1) * W3_BUF;
+        const bool pf = tile + p.S < p.ntiles && !(p.abl & 1);
+        TileAddr ta{};
+        if (pf) ta = tile_addr(tile + p.S);
+        if (!active) {
+            if (pf) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) issue_group(ta, nxt, g);
+            }
+            if (dobias) {
+#pragma unroll 4
+                for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) bsum[mt] += cur[aBase + mt * 16 * WG_PSO + (j >> 3) * WG_TW + (j & 7) * 4];
+                }
+            }
+            continue;
+        }
+        // 16 k-steps (4 consecutive pixels each): the LDS reads of k-step n+1 are in flight while the 15 MFMAs of
+        // k-step n issue; DMA group g goes out at the start of k-step 2g
+        float A0[5], B0[3], A1[5], B1[3];
+        auto ld = [&](int j, float (&A)[5], float (&Bv)[3]) {
+            const float* ca = cur + aBase + (j >> 3) * WG_TW + (j & 7) * 4;
+            const float* cbv = cur + bBase + (j >> 3) * WG_IRS + (j & 7) * 4;
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) A[mt] = ca[mt * 16 * WG_PSO];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) Bv[t] = cbv[t];
+        };
+        auto mm = [&](const float (&A)[5], const float (&Bv)[3]) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt)
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mt], Bv[t], acc[mt][t], 0, 0, 0);
+        };
+        ld(0, A0, B0);
+#pragma unroll 1
+        for (int j2 = 0; j2 < 8; ++j2) {
+            if (pf && j2 < NG) issue_group(ta, nxt, j2);
+            ld(2 * j2 + 1, A1, B1);
+            mm(A0, B0);
+            if (j2 < 7) ld(2 * j2 + 2, A0, B0);
+            mm(A1, B1);
+        }
+    }
+
+    // ---- every wave owns its slab: one atomic per element; the pixel splits meet in L2 / memory ----
+    // scr != 0: [co][tap][ci] staging slab, 16 lanes of a wave hit one 64-byte line (coalesced atomics);
+    // scr == 0: straight into the [co][ci][tap] gradient (36-byte lane stride).
+    if (active && !(p.abl & 2)) {
+        const int ci = ci0 + cit * 16 + l16;
+        if (ci < p.Cin) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // C layout: col = lane&15 -> ci (N), row = (lane>>4)*4 + r -> co (M)
+                    const int co = cb * W3_C + mt * 16 + kq * 4 + r;
+                    if (p.scr) {
+                        float* g = p.gw + ((size_t)co * 9 + trw * 3) * p.Cin + ci;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) atomicAdd(g + (size_t)t * p.Cin, acc[mt][t][r]);
+                    } else {
+                        float* g = p.gw + ((size_t)co * p.Cin + ci) * 9 + trw * 3;
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) atomicAdd(g + t, acc[mt][t][r]);
+                    }
+                }
+        }
+    }
+    if (dobias) {
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            float v = bsum[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) atomicAdd(&p.gb[cb * W3_C + mt * 16 + l16], v);
+        }
+    }
+}
+
+// gw[co][ci][tap] += scr[co][tap][ci]   (unpacks the staging slab of wgrad3x3_kernel)
+__global__ void wgrad_unstage_kernel(const float* __restrict__ scr, float* __restrict__ gw, int Cin, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // index into gw
+    if (i >= n) return;
+    const int t = i % 9;
+    const int rest = i / 9;
+    const int ci = rest % Cin, co = rest / Cin;
+    gw[i] += scr[((size_t)co * 9 + t) * Cin + ci];
+}
+
 template <int MT, int TAPS>
 static void wgrad_launch_t(const WgradArgs& a, unsigned grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (MT * 16 * WG_PSO + WG_CI * WG_PSI) * sizeof(float);
@@ -188,11 +383,45 @@ static void wgrad_launch_t(const WgradArgs& a, unsigned grid, hipStream_t st) {
 }
 
 static int wgrad_launch(const float* zero, const float* dout, const float* in, float* gw, float* gb, int B, int H, int W,
-                        int Cin, int Cout, int taps, hipStream_t st) {
+                        int Cin, int Cout, int taps, hipStream_t st, float* scr = nullptr) {
     WgradArgs a{};
     a.zero = zero;
     a.dout = dout; a.in = in; a.gw = gw; a.gb = gb;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    static const int abl = getenv("SINDDM_WGRAD_ABL") ? atoi(getenv("SINDDM_WGRAD_ABL")) : 0;
+    static const int w3 = getenv("SINDDM_WGRAD_W3") ? atoi(getenv("SINDDM_WGRAD_W3")) : 1;
+    a.abl = abl;
+    a.tilesX = (W + WG_TW - 1) / WG_TW;
+    a.tilesY = (H + WG_TH - 1) / WG_TH;
+    a.ntiles = B * a.tilesX * a.tilesY;
+    if (taps == 9 && Cout % W3_C == 0 && w3) {
+        // one workgroup per CU; the largest per-sample channel slab must stay below the buffer OOB marker
+        if ((size_t)W3_C * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
+        a.coblks = Cout / W3_C;
+        a.ciblks = (Cin + W3_C - 1) / W3_C;
+        const int pairs = a.coblks * a.ciblks;
+        int S = (device_cu_count() / pairs) / 8 * 8;
+        if (S < 8) S = 8;
+        const int cap = (a.ntiles + 7) / 8 * 8;
+        if (S > cap) S = cap;
+        a.S = S;
+        constexpr size_t lds = (size_t)2 * W3_BUF * sizeof(float);
+        static const int stage = getenv("SINDDM_WGRAD_STAGE") ? atoi(getenv("SINDDM_WGRAD_STAGE")) : 1;
+        const int n = Cout * Cin * 9;
+        if (scr && stage) {
+            hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+            a.gw = scr;
+            a.scr = 1;
+        }
+        hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(pairs * S)), dim3(W3_THREADS), lds, st, a);
+        SINDDM_LAUNCH_CHECK();
+        if (a.scr) {
+            hipLaunchKernelGGL(wgrad_unstage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scr, gw, Cin, n);
+            SINDDM_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int mt = mt_for(Cout);
     a.coblks = (Cout + mt * 16 - 1) / (mt * 16);
     a.ciblks = (Cin + WG_CI - 1) / WG_CI;
@@ -568,6 +797,7 @@ static size_t carve_train(const NetPlan& P, int B, int H, int W, char* base, Tra
     for (int i = 0; i < 4; ++i) t.s[i] = take((size_t)B * P.dim * HW);
     t.dcond = take((size_t)B * P.cond_stride);
     t.small = take((size_t)B * (128 + 32 + 128));
+    t.wscr = take((size_t)P.dim * P.dim * 9);
     if (tb) *tb = t;
     return off;
 }
@@ -617,7 +847,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         float* dX = tb.s[(di + 3) & 3];
         const int nchK = (b.cout + KC - 1) / KC;
         // conv2 + residual projection weight grads
-        rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st);
+        rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr);
         if (rc) return rc;
         if (b.res_w >= 0) {
             rc = wgrad_launch(zp, dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
@@ -631,7 +861,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
                                 b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
         if (rc) return rc;
         // conv1 weight grads, dH = dgrad_conv1(dU)
-        rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st);
+        rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
         if (rc) return rc;
         if (wino_enabled() && k.wdg1[l] >= 0)
             rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], nullptr, 0, dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
