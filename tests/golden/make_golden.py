@@ -21,6 +21,8 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g10_train.npz      20 train() steps with injected (s, t, noise), dim=32
   g11_img_scales.json create_img_scales() integer/float64 bookkeeping for all datasets
   c1_pyramid.npz     the C1 balloons pyramid (uint8 images) the trainer fixtures use
+  g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
+  g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
 """
 import contextlib
 import json
@@ -420,7 +422,63 @@ def g10(meta, workdir):
     save("g10_train.npz", **out)
 
 
+def g12(workdir):
+    """Checkpoint interop: the reference trains 3 steps (its own RNG), save()s model-1.pt, load()s it into a fresh
+    trainer and evaluates the EMA network / one reverse step on recorded inputs."""
+    cfg = CONFIGS["C1"]
+    dst, fname, sizes, losses, sf, n = run_create_img_scales(cfg, os.path.join(workdir, "G12"))
+    dim = 16
+
+    def build(results):
+        net = rm.SinDDMNet(dim=dim, multiscale=True, device=DEV)
+        d = make_diffusion(net, sizes, losses, sf, n, cfg["T"])
+        tr = rt.MultiscaleTrainer(d, folder=dst, n_scales=n, scale_factor=sf, image_sizes=sizes, train_batch_size=2,
+                                  train_lr=1e-3, train_num_steps=3, gradient_accumulate_every=1, ema_decay=0.9,
+                                  fp16=False, step_start_ema=1, update_ema_every=1, save_and_sample_every=10 ** 9,
+                                  avg_window=1, sched_milestones=[2], results_folder=results, device=DEV)
+        return tr
+
+    res = tempfile.mkdtemp()
+    torch.manual_seed(20240612)
+    tr = build(res)
+    tr.train()
+    tr.save(1)
+    shutil.copy(os.path.join(res, "model-1.pt"), os.path.join(HERE, "g12_model-1.pt"))
+    # a fresh reference trainer loads the file and evaluates
+    tr2 = build(res)
+    tr2.load(1)
+    em = tr2.ema_model
+    x = hash_randn((2, 3, 37, 41), 1201)
+    t = torch.tensor([3, 57], dtype=torch.long)
+    with torch.no_grad():
+        y_ema = em.denoise_fn(x, t, scale=1)
+        y_model = tr2.model.denoise_fn(x, t, scale=1)
+    s = 1
+    H, W = em.image_sizes[s]
+    xt = hash_randn((2, 3, H, W), 1202)
+    em.img_prev_upsample = hash_randn((2, 3, H, W), 1203).clamp(-1, 1)
+    z = hash_randn((2, 3, H, W), 1204)
+    o_noise_like = rm.noise_like
+    rm.noise_like = lambda shape, device, repeat=False, _z=z: _z
+    try:
+        with torch.no_grad():
+            x_prev = em.p_sample(xt, torch.full((2,), 17, dtype=torch.long), s)
+    finally:
+        rm.noise_like = o_noise_like
+    # inputs are hash noise (keys 1201..1204 above): only the reference's outputs are stored
+    save("g12_ckpt.npz", t=t, y_ema=y_ema, y_model=y_model, step=np.array(tr2.step),
+         lr=np.array(tr2.opt.param_groups[0]["lr"]), sched_last_epoch=np.array(tr2.scheduler.last_epoch),
+         sizes=np.array(sizes), losses=np.array(losses), sf=np.array(sf), x_prev=x_prev)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+        workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
+        try:
+            g12(workdir)
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+        return
     workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
     try:
         meta = g1_g11(workdir)
@@ -432,6 +490,7 @@ def main():
         g8()
         g9(meta)
         g10(meta, workdir)
+        g12(workdir)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

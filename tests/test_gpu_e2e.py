@@ -98,3 +98,46 @@ def test_train_then_checkpoint_roundtrip(golden, tmp_path):
     # the loaded EMA model samples (packed weights are rebuilt from the loaded parameters)
     x = tr2.ema_model.sample(batch_size=1)
     assert torch.isfinite(x).all()
+
+
+def test_load_reference_checkpoint(golden, tmp_path):
+    """G12 / SURVEY 8(f) row 1: `MultiscaleTrainer.load()` reads a model-N.pt written by the REFERENCE trainer
+    (same key names) and the HIP path reproduces what the reference computes from it."""
+    import shutil
+    from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
+    from sinddm_amd.trainer import MultiscaleTrainer
+    g = golden("g12_ckpt.npz")
+    pyr = golden("c1_pyramid.npz")
+    folder = str(tmp_path / "balloons") + "/"
+    for key in pyr.files:
+        os.makedirs(folder + key, exist_ok=True)
+        Image.fromarray(pyr[key]).save(folder + key + "/balloons.png")
+    res = tmp_path / "res"
+    res.mkdir()
+    shutil.copy(os.path.join(os.path.dirname(__file__), "golden", "g12_model-1.pt"), str(res / "model-1.pt"))
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    net = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    d = MultiScaleGaussianDiffusion(net, n_scales=3, scale_factor=float(g["sf"]), image_sizes=sizes, timesteps=100,
+                                    train_full_t=True, scale_losses=[float(v) for v in g["losses"]], loss_factor=1,
+                                    loss_type="l1", device=DEV, reblurring=True, omega=0).to(DEV)
+    tr = MultiscaleTrainer(d, folder=folder, n_scales=3, scale_factor=float(g["sf"]), image_sizes=sizes,
+                           train_batch_size=2, train_lr=1e-3, train_num_steps=3, gradient_accumulate_every=1,
+                           ema_decay=0.9, fp16=False, step_start_ema=1, update_ema_every=1,
+                           save_and_sample_every=10 ** 9, avg_window=1, sched_milestones=[2],
+                           results_folder=str(res), device=DEV)
+    tr.load(1)
+    assert tr.step == int(g["step"])
+    assert tr.scheduler.last_epoch == int(g["sched_last_epoch"])
+    assert abs(tr.opt.param_groups[0]["lr"] - float(g["lr"])) < 1e-12
+    x = hash_randn((2, 3, 37, 41), 1201).to(DEV)
+    t = torch.from_numpy(g["t"]).to(DEV)
+    with torch.no_grad():
+        assert rel_l2(tr.ema_model.denoise_fn(x, t, scale=1).cpu(), g["y_ema"]) < 1e-5
+        assert rel_l2(tr.model.denoise_fn(x, t, scale=1).cpu(), g["y_model"]) < 1e-5
+    H, W = 67, 90
+    em = tr.ema_model
+    em.img_prev_upsample = hash_randn((2, 3, H, W), 1203).clamp(-1, 1).to(DEV)
+    z = hash_randn((2, 3, H, W), 1204).to(DEV)
+    em.noise_fn = lambda kind, shape, s, t, device: z
+    y = em.p_sample(hash_randn((2, 3, H, W), 1202).to(DEV), torch.full((2,), 17, dtype=torch.long, device=DEV), 1)
+    assert rel_l2(y.cpu(), g["x_prev"]) < 1e-5

@@ -159,3 +159,31 @@ def test_adam_and_lr_restatement():
         sch.step()
         O.adam_step(p, g, m, v, n, lr)
         assert max_abs(p, ref.detach()) < 1e-7
+
+
+def test_g12_reference_checkpoint(golden):
+    """G12: a model-1.pt written by the reference trainer's save(): key set, and the oracle evaluated with its
+    (trained, non-closed-form) weights reproduces what the reference computes after load()."""
+    import os
+    from sinddm_amd.synth import hash_randn
+    g = golden("g12_ckpt.npz")
+    ck = torch.load(os.path.join(os.path.dirname(__file__), "golden", "g12_model-1.pt"), map_location="cpu",
+                    weights_only=False)
+    assert set(ck) == {"step", "model", "ema", "sched", "running_loss", "running_scale"}     # trainer.py:162-170
+    assert int(ck["step"]) == int(g["step"]) == 3
+    x = hash_randn((2, 3, 37, 41), 1201)
+    t = torch.from_numpy(g["t"])
+    for which, key in (("ema", "y_ema"), ("model", "y_model")):
+        sd = {k[len("denoise_fn."):]: v for k, v in ck[which].items() if k.startswith("denoise_fn.")}
+        assert len(sd) == 52
+        y = O.net_forward(sd, x, t, 1)
+        assert rel_l2(y, g[key]) < 2e-6, which
+    # the diffusion buffers in the file are the schedule the oracle derives from (T, losses)
+    sched = O.make_schedule(100, 3, [float(v) for v in g["losses"]], loss_factor=1, train_full_t=True)
+    for name in ("betas", "sqrt_alphas_cumprod", "posterior_mean_coef1", "gammas"):
+        assert np.array_equal(ck["ema"][name].numpy(), np.asarray(sched[name], dtype=np.float32)), name
+    sd = {k[len("denoise_fn."):]: v for k, v in ck["ema"].items() if k.startswith("denoise_fn.")}
+    H, W = 67, 90
+    xt, xtil, z = hash_randn((2, 3, H, W), 1202), hash_randn((2, 3, H, W), 1203).clamp(-1, 1), hash_randn((2, 3, H, W), 1204)
+    y = O.p_sample(sched, sd, xt, 17, 1, z, xtil)
+    assert rel_l2(y, g["x_prev"]) < 5e-6
