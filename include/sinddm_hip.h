@@ -93,6 +93,14 @@ int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde
                         const float* noise, float* out, const sinddm_step_coefs* coefs /*host*/,
                         int64_t n, void* stream);
 
+/* Same step with the reference's ROI guidance folded in (roi_patch_modification, models.py:291-298, applied at
+ * :430-431 when roi_guided_sampling and s < n_scales-1): the predicted clean image x_recon becomes
+ * edit_w[p] * x_recon + edit_c[ch][p] before the re-blur mix and the clamps.  edit_w: HW floats, edit_c: C*HW
+ * floats (shared by all B samples, like the reference's broadcast target patch). */
+int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_tilde,
+                             const float* noise, float* out, const sinddm_step_coefs* coefs /*host*/,
+                             const float* edit_w, const float* edit_c, int B, int C, int HW, void* stream);
+
 /* F.interpolate(in, size=(H,W), mode='bilinear') (align_corners=False)  models.py:567 */
 int sinddm_upsample_bilinear(const float* in, float* out, int BC, int h, int w, int H, int W,
                              void* stream);

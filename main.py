@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Command line of the MI355X SinDDM hot-path build: same flags as the reference's main.py
-(reference main.py:13-58) for the two hot-path modes, `train` and `sample`.
+(reference main.py:13-58) for the modes that run on the hot path: `train`, `sample`, `style_transfer`,
+`harmonization` and `roi`.
 
     python main.py --scope balloons --mode train  --dataset_folder ./datasets/balloons/ --image_name balloons.png
     python main.py --scope balloons --mode sample --dataset_folder ./datasets/balloons/ --image_name balloons.png \
@@ -10,8 +11,11 @@ Multi-GPU sampling: launch one process per GPU with torchrun; the sample batch i
 ranks as independent chains and all-gathered (RCCL over xGMI):
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 main.py --mode sample ...
 
-The guided / application modes of the reference (clip_*, roi, harmonization, style_transfer;
-reference main.py:153-320) depend on CLIP, cv2 GUIs and skimage and are outside this build.
+`style_transfer` / `harmonization` (reference main.py:296-322) drive `MultiscaleTrainer.image2image`; `roi`
+(main.py:257-294) drives `roi_guided_sampling` -- the reference picks the boxes with a cv2 GUI, here they come from
+`--roi_target y x h w` and `--roi_bbs y x h w [y x h w ...]` (finest-scale pixel coordinates).
+The CLIP-guided modes (clip_content, clip_style_*, clip_roi; main.py:153-255) need CLIP autograd and are outside
+this build.
 """
 import argparse
 import os
@@ -39,6 +43,8 @@ _FLAGS = [
     ("sched_k_milestones", [20, 40, 70, 80, 90, 110], int, "+"), ("load_milestone", 0, int, None),
     ("sample_batch_size", 16, int, None), ("scale_mul", [1, 1], float, "+"), ("sample_t_list", None, int, "+"),
     ("device_num", 0, int, None), ("omega", 0, float, None), ("loss_factor", 1, float, None),
+    # non-interactive stand-ins for the cv2.selectROI dialogs of the reference's `roi` mode
+    ("roi_target", None, int, "+"), ("roi_bbs", None, int, "+"),
 ]
 
 
@@ -100,10 +106,27 @@ def main():
     elif args.mode == 'sample':
         trainer.sample_scales(scale_mul=scale_mul, custom_sample=True, image_name=args.image_name,
                               batch_size=args.sample_batch_size, custom_t_list=sample_t_list, save_unbatched=True)
+    elif args.mode in ('style_transfer', 'harmonization'):                 # reference main.py:296-322
+        i2i_folder = os.path.join(args.dataset_folder, 'i2i')
+        start_s = n_scales - 1                                             # start the diffusion at the last scale
+        start_t = args.start_t_style if args.mode == 'style_transfer' else args.start_t_harm
+        use_hist = args.mode == 'style_transfer'
+        custom_t = [0] * (n_scales - 1) + [start_t]
+        trainer.ema_model.reblurring = True
+        trainer.image2image(input_folder=i2i_folder, input_file=args.input_image, mask=args.harm_mask,
+                            hist_ref_path=f'{args.dataset_folder}scale_{start_s}/', batch_size=args.sample_batch_size,
+                            image_name=args.image_name, start_s=start_s, custom_t=custom_t, scale_mul=(1, 1),
+                            device=device, use_hist=use_hist, save_unbatched=True, auto_scale=50000, mode=args.mode)
+    elif args.mode == 'roi':                                               # reference main.py:257-294
+        if not args.roi_target or len(args.roi_target) != 4 or not args.roi_bbs or len(args.roi_bbs) % 4:
+            raise SystemExit("--mode roi needs --roi_target y x h w and --roi_bbs y x h w [y x h w ...]")
+        bbs = [list(args.roi_bbs[i:i + 4]) for i in range(0, len(args.roi_bbs), 4)]
+        trainer.roi_guided_sampling(custom_t_list=sample_t_list, target_roi=list(args.roi_target), roi_bb_list=bbs,
+                                    save_unbatched=True, batch_size=args.sample_batch_size, scale_mul=scale_mul)
     else:
         raise NotImplementedError(
-            f"mode {args.mode!r}: only 'train' and 'sample' (the SinDDM hot path) are built for MI355X; the CLIP / ROI / "
-            "harmonization / style-transfer modes of the reference are out of scope (SURVEY.md section 8)")
+            f"mode {args.mode!r}: train, sample, style_transfer, harmonization and roi are built for MI355X; the CLIP-guided "
+            "modes of the reference need CLIP autograd and are out of scope (SURVEY.md section 8)")
     if world > 1:
         import torch.distributed as td
         td.destroy_process_group()

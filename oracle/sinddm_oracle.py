@@ -187,24 +187,43 @@ def p_losses(sched: dict, sd: Dict[str, Tensor], x_start: Tensor, t: Tensor, s: 
     return (noise - eps).abs().mean()
 
 
+def roi_patch_modification(x_recon: Tensor, roi_bbs, target_patch: Tensor, scale_factor: float, n_scales: int,
+                           scale: int, eta: float = 0.8) -> Tensor:
+    """models.py:291-298: inside every box (given at finest-scale coordinates, rescaled with int() truncation) the
+    predicted clean image is blended with the nearest-resized target patch, sequentially over the boxes."""
+    x = x_recon.clone()
+    for bb in roi_bbs:
+        bb = [int(b / np.power(scale_factor, n_scales - scale - 1)) for b in bb]
+        y, xx, h, w = bb
+        patch = F.interpolate(target_patch, size=(h, w))
+        x[:, :, y:y + h, xx:xx + w] = eta * patch + (1 - eta) * x[:, :, y:y + h, xx:xx + w]
+    return x
+
+
 def reverse_step(sched: dict, x: Tensor, eps: Tensor, t: int, s: int, noise: Tensor,
                  x_tilde: Optional[Tensor], reblurring: bool = True, omega: float = 0.0,
-                 clip_denoised: bool = True) -> Tensor:
+                 clip_denoised: bool = True, x_recon_edit=None) -> Tensor:
     """Everything in p_sample after the net call: predict_start_from_noise
     (models.py:306-318) + the normal-sampling branch of p_mean_variance (:433-447)
     + q_posterior (:321-352) + the noise add of p_sample (:455-459).
-    All samples share the integer timestep `t` (models.py:481,541)."""
+    All samples share the integer timestep `t` (models.py:481,541).
+    `x_recon_edit`: optional callable applied to x_recon where the reference applies
+    roi_patch_modification (models.py:430-431)."""
     B = x.shape[0]
     tt = torch.full((B,), int(t), dtype=torch.long)
     x0 = extract(sched["sqrt_recip_alphas_cumprod"], tt) * x - extract(sched["sqrt_recipm1_alphas_cumprod"], tt) * eps
     plain = (not reblurring) or int(s) == 0
     if plain:
+        if x_recon_edit is not None:
+            x0 = x_recon_edit(x0)          # x_recon and x_t_mix are one tensor here (models.py:311-312)
         x_tm1_mix = x0
         x_t_mix = x0
     else:
         cur_g = sched["gammas"][s - 1].reshape(-1).clamp(0, 0.55)
         g_t = extract(cur_g, tt)
         x_tm1_mix = (x0 - g_t * x_tilde) / (1 - g_t)
+        if x_recon_edit is not None:
+            x_tm1_mix = x_recon_edit(x_tm1_mix)
         x_t_mix = x0
     # models.py:434-438
     if int(s) > 0 and t > 0 and reblurring:
@@ -288,17 +307,25 @@ def scale_size(image_sizes_hw, n_scales, scale_factor, s, scale_mul=(1, 1), cust
 
 def sample_chain(sched: dict, sd: Dict[str, Tensor], sizes_hw: Sequence[Tuple[int, int]],
                  noises: dict, batch: int, custom_t_list: Optional[Sequence[int]] = None,
-                 trace: Optional[list] = None) -> List[Tensor]:
+                 trace: Optional[list] = None, roi: Optional[dict] = None) -> List[Tensor]:
     """Full multi-scale sampling, trainer.py:226-285 -> models.py:463-568, with every
     random draw supplied through `noises`:
       noises[("init", 0)]           (B,3,H0,W0)  the randn of models.py:467
       noises[("renoise", s)]        (B,3,Hs,Ws)  the q_sample noise of models.py:518
       noises[("step", s, t)]        (B,3,Hs,Ws)  the randn of models.py:455
-    Returns the per-scale outputs.  `trace` collects (s, total_t, [t...]) bookkeeping."""
+    Returns the per-scale outputs.  `trace` collects (s, total_t, [t...]) bookkeeping.
+    `roi` = dict(bbs, target_patch[per scale], scale_factor) turns on ROI guided sampling."""
     n_scales = len(sizes_hw)
     ideal = sched["num_timesteps_ideal"]
     if custom_t_list is None:
         custom_t_list = ideal[1:]
+    def edit(s):
+        # ROI guidance (trainer.py:436-454 -> models.py:430-431): every scale but the finest
+        if roi is None or not (s < n_scales - 1):
+            return None
+        return lambda xr: roi_patch_modification(xr, roi["bbs"], roi["target_patch"][s], roi["scale_factor"],
+                                                 n_scales, s)
+
     outs = []
     T = sched["num_timesteps"]
     img = noises[("init", 0)].clone()
@@ -306,7 +333,7 @@ def sample_chain(sched: dict, sd: Dict[str, Tensor], sizes_hw: Sequence[Tuple[in
     if trace is not None:
         trace.append((0, T, ts))
     for t in ts:
-        img = p_sample(sched, sd, img, t, 0, noises[("step", 0, t)], None)
+        img = p_sample(sched, sd, img, t, 0, noises[("step", 0, t)], None, x_recon_edit=edit(0))
     outs.append(img)
     for s in range(1, n_scales):
         up = bilinear_upsample(outs[-1], sizes_hw[s])
@@ -317,7 +344,7 @@ def sample_chain(sched: dict, sd: Dict[str, Tensor], sizes_hw: Sequence[Tuple[in
         if trace is not None:
             trace.append((s, total_t, ts))
         for t in ts:
-            img = p_sample(sched, sd, img, t, s, noises[("step", s, t)], up)
+            img = p_sample(sched, sd, img, t, s, noises[("step", s, t)], up, x_recon_edit=edit(s))
         outs.append(img)
     return outs
 

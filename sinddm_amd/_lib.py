@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsinddm_hip.so")
 ABI_SYMBOLS = (
     "sinddm_abi_version", "sinddm_param_count", "sinddm_param_tensors", "sinddm_param_offset",
     "sinddm_packed_count", "sinddm_workspace_bytes", "sinddm_pack_weights", "sinddm_net_forward",
-    "sinddm_q_sample", "sinddm_reverse_step", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2",
+    "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
 )
@@ -63,6 +63,7 @@ def load() -> C.CDLL:
         "sinddm_net_forward": (i, [p, p, p, p, i, f, p, i, i, i, i, p, sz, p]),
         "sinddm_q_sample": (i, [p, p, p, p, p, p, p, p, i, i, i64, p]),
         "sinddm_reverse_step": (i, [p, p, p, p, p, C.POINTER(StepCoefs), i64, p]),
+        "sinddm_reverse_step_edit": (i, [p, p, p, p, p, C.POINTER(StepCoefs), p, p, i, i, i, p]),
         "sinddm_upsample_bilinear": (i, [p, p, i, i, i, i, i, p]),
         "sinddm_prof_begin": (i, []),
         "sinddm_prof_end": (i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

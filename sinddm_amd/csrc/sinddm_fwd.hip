@@ -360,19 +360,33 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
     }
 }
 
+// EDIT: the predicted clean image is replaced by  w(p) * x_recon + c(ch, p)  before the re-blur mix / clamps --
+// the ROI-guided sampling of the reference (models.py:291-298,430-431) written as a per-pixel affine map
+// (sequential `eta*patch + (1-eta)*x` blends over possibly overlapping boxes compose into one such map).
+template <bool EDIT>
 __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restrict__ xt, const float* __restrict__ eps,
                                                            const float* __restrict__ xtil, const float* __restrict__ z,
-                                                           float* __restrict__ out, sinddm_step_coefs k, long long n) {
+                                                           float* __restrict__ out, sinddm_step_coefs k, long long n,
+                                                           const float* __restrict__ ew, const float* __restrict__ ec,
+                                                           int chw, int hw) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float x = xt[i];
-        const float x0 = k.sqrt_recip_ac_t * x - k.sqrt_recipm1_ac_t * eps[i];   // models.py:308-309
+        float x0 = k.sqrt_recip_ac_t * x - k.sqrt_recipm1_ac_t * eps[i];         // models.py:308-309
+        float w = 1.0f, c = 0.0f;
+        if (EDIT) {
+            const int q = (int)(i % chw);
+            w = ew[q % hw];
+            c = ec[q];
+        }
         float mean;
         if (k.mode == 0) {
+            if (EDIT) x0 = w * x0 + c;          // x_recon and x_t_mix are the same tensor here (models.py:311-312)
             const float x0c = k.clip ? fminf(fmaxf(x0, -1.0f), 1.0f) : x0;
             mean = k.coef1_t * x0c + k.coef2_t * x;                               // models.py:324-327
         } else {
             const float xb = xtil[i];
             float xp = (x0 - k.gamma_t * xb) / (1.0f - k.gamma_t);                // models.py:315-316
+            if (EDIT) xp = w * xp + c;
             if (k.mode == 1) {
                 float mix = k.gamma_tm1 * xb + (1.0f - k.gamma_tm1) * xp;         // models.py:435-436
                 float x0c = x0;
@@ -583,8 +597,24 @@ int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde
     if (coefs->mode != 0 && !x_tilde) return SINDDM_E_BADARG;
     long long bx = (n + 255) / 256;
     if (bx > 8192) bx = 8192;
-    hipLaunchKernelGGL(reverse_step_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), x_t,
-                       eps, x_tilde, noise, out, *coefs, (long long)n);
+    hipLaunchKernelGGL(reverse_step_kernel<false>, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x_t, eps, x_tilde, noise, out, *coefs, (long long)n, nullptr, nullptr, 1, 1);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_tilde, const float* noise, float* out,
+                             const sinddm_step_coefs* coefs, const float* edit_w, const float* edit_c, int B, int C,
+                             int HW, void* stream) {
+    if (!x_t || !eps || !noise || !out || !coefs || !edit_w || !edit_c || B <= 0 || C <= 0 || HW <= 0)
+        return SINDDM_E_BADARG;
+    if (coefs->mode != 0 && !x_tilde) return SINDDM_E_BADARG;
+    if ((long long)C * HW > 0x7fffffffLL) return SINDDM_E_BADSHAPE;
+    const long long n = (long long)B * C * HW;
+    long long bx = (n + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(reverse_step_kernel<true>, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x_t, eps, x_tilde, noise, out, *coefs, n, edit_w, edit_c, C * HW, HW);
     SINDDM_LAUNCH_CHECK();
     return 0;
 }

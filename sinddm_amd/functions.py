@@ -120,3 +120,65 @@ def create_img_scales(foldername, filename, scale_factor=1.411, image_size=None,
             out_dir.mkdir(parents=True, exist_ok=True)
             recon.save(str(out_dir / filename))
     return sizes, rescale_losses, scale_factor, n_scales
+
+
+# ---- helpers of the application drivers (reference SinDDM/functions.py:21-48) ----------------------------
+def extract_patch(image: torch.Tensor, bb) -> torch.Tensor:              # functions.py:45-48
+    y_bb, x_bb, h_bb, w_bb = bb
+    return image[:, :, y_bb:y_bb + h_bb, x_bb:x_bb + w_bb]
+
+
+def stat_from_bbs(image: torch.Tensor, bb):                              # functions.py:38-42
+    y_bb, x_bb, h_bb, w_bb = bb
+    reg = image[:, :, y_bb:y_bb + h_bb, x_bb:x_bb + w_bb]
+    return [torch.mean(reg, dim=(2, 3), keepdim=True), torch.std(reg, dim=(2, 3), keepdim=True)]
+
+
+def _disk(radius: int) -> np.ndarray:
+    """skimage.morphology.disk: (2r+1)^2 footprint of the pixels within Euclidean distance r."""
+    yy, xx = np.mgrid[-radius:radius + 1, -radius:radius + 1]
+    return (xx * xx + yy * yy) <= radius * radius
+
+
+def dilate_mask(mask: torch.Tensor, mode: str) -> np.ndarray:
+    """functions.py:21-33 -- binary dilation by a disk (radius 7 harmonization / 20 editing), Gaussian blur
+    (sigma 5), min-max normalisation; returns (1,1,H,W).  The reference calls scikit-image 0.19.3 (absent from this
+    image and from the build container, so this function is NOT pinned by a reference run): restated here on
+    scipy.ndimage with scikit-image's documented defaults (binary_dilation: border value False;
+    filters.gaussian: mode='nearest', truncate=4.0, float64)."""
+    from scipy import ndimage as ndi
+    if mode == "harmonization":
+        element = _disk(7)
+    elif mode == "editing":
+        element = _disk(20)
+    else:
+        raise ValueError(mode)
+    m = np.asarray(mask.permute(1, 2, 0)[:, :, 0]) != 0
+    m = ndi.binary_dilation(m, structure=element)
+    m = ndi.gaussian_filter(m.astype(np.float64), sigma=5, mode="nearest", truncate=4.0)
+    m = m[None, None, :, :]
+    return (m - m.min()) / (m.max() - m.min())
+
+
+def match_histograms(image: np.ndarray, reference: np.ndarray, channel_axis: int = 2) -> np.ndarray:
+    """skimage.exposure.match_histograms (0.19.3) for uint8 HxWxC images, as used by image2image
+    (trainer.py:312-314): per channel, map every source level through the reference's inverse CDF
+    (np.interp of the cumulative histograms) and store into the input dtype.  Not pinned by a reference run
+    (scikit-image is absent here); restated from the published algorithm."""
+    if image.ndim != reference.ndim or channel_axis != image.ndim - 1:
+        raise ValueError("expects HxWxC arrays with the channel axis last")
+    if image.shape[-1] != reference.shape[-1]:
+        raise ValueError("Number of channels in the input image and reference image must match!")
+    out = np.empty(image.shape, dtype=image.dtype)
+    for ch in range(image.shape[-1]):
+        src, tmpl = image[..., ch], reference[..., ch]
+        lookup = src.reshape(-1)
+        src_counts = np.bincount(lookup)
+        tmpl_counts = np.bincount(tmpl.reshape(-1))
+        tmpl_values = np.nonzero(tmpl_counts)[0]
+        tmpl_counts = tmpl_counts[tmpl_values]
+        src_q = np.cumsum(src_counts) / src.size
+        tmpl_q = np.cumsum(tmpl_counts) / tmpl.size
+        interp = np.interp(src_q, tmpl_q, tmpl_values)
+        out[..., ch] = interp[lookup].reshape(src.shape)
+    return out

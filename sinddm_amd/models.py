@@ -22,6 +22,7 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import _lib
@@ -335,6 +336,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
         self.roi_bbs = []
         self.roi_bbs_stat = []
         self.roi_target_patch = []
+        self._roi_cache = {}
 
         # (W,H) -> (H,W)   models.py:222-223
         self.image_sizes = tuple((image_sizes[i][1], image_sizes[i][0]) for i in range(n_scales))
@@ -474,11 +476,37 @@ class MultiScaleGaussianDiffusion(nn.Module):
             logvar = extract(self.posterior_log_variance_clipped, t, x_t.shape)
         return mean, var, logvar
 
-    def p_mean_variance(self, x, t, s, clip_denoised: bool):               # models.py:354-447 (normal branch)
-        if self.clip_guided_sampling or self.roi_guided_sampling:
-            raise NotImplementedError("CLIP / ROI guided sampling is outside the MI355X hot-path build")
+    def roi_patch_modification(self, x_recon, scale=0, eta=0.8):            # models.py:291-298 (in place, like it)
+        w, c = self.roi_edit_maps(scale, x_recon.shape[-2], x_recon.shape[-1], x_recon.device, eta)
+        x_recon.mul_(w[None, None]).add_(c[None])
+        return x_recon
+
+    def roi_edit_maps(self, scale: int, H: int, W: int, device, eta: float = 0.8):
+        """The reference's sequential ROI blends `x[box] = eta * patch + (1 - eta) * x[box]` over all boxes
+        (models.py:291-298) composed into ONE per-pixel affine map x -> w * x + c (w: (H,W), c: (3,H,W)); this is
+        what the fused reverse-step kernel applies (`sinddm_reverse_step_edit`).  Cached per (scale, size, boxes)."""
+        key = (int(scale), int(H), int(W), float(eta), tuple(tuple(int(v) for v in bb) for bb in self.roi_bbs),
+               id(self.roi_target_patch[scale]))
+        if self._roi_cache.get("key") == key:
+            return self._roi_cache["w"], self._roi_cache["c"]
+        w = torch.ones((H, W), device=device, dtype=torch.float32)
+        c = torch.zeros((self.channels, H, W), device=device, dtype=torch.float32)
+        for bb in self.roi_bbs:                                             # bounding box is [y, x, h, w]
+            bb = [int(bb_i / np.power(self.scale_factor, self.n_scales - scale - 1)) for bb_i in bb]
+            y, x, h, ww = bb
+            patch = F.interpolate(self.roi_target_patch[scale].to(device=device, dtype=torch.float32), size=(h, ww))[0]
+            c[:, y:y + h, x:x + ww] = eta * patch + (1 - eta) * c[:, y:y + h, x:x + ww]
+            w[y:y + h, x:x + ww] *= (1 - eta)
+        self._roi_cache = {"key": key, "w": w.contiguous(), "c": c.contiguous()}
+        return self._roi_cache["w"], self._roi_cache["c"]
+
+    def p_mean_variance(self, x, t, s, clip_denoised: bool):               # models.py:354-447 (normal + ROI branch)
+        if self.clip_guided_sampling:
+            raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
         eps = self._eps(x, t, int(t[0]), s)
         x_recon, x_t_mix = self.predict_start_from_noise(x, t=t, s=s, noise=eps)
+        if self.roi_guided_sampling and (s < self.n_scales - 1):           # models.py:430-431
+            x_recon = self.roi_patch_modification(x_recon, scale=s)
         if int(s) > 0 and t[0] > 0 and self.reblurring:
             g = extract(self.gammas[s - 1].reshape(-1).clamp(0, 0.55), t - 1, x_recon.shape)
             x_tm1_mix = g * self.img_prev_upsample + (1 - g) * x_recon
@@ -515,14 +543,21 @@ class MultiScaleGaussianDiffusion(nn.Module):
                 raise _lib.SinddmError("img_prev_upsample is not set (call sample_via_scale / p_sample_via_scale_loop)")
             xt = xt.contiguous()
         out = torch.empty_like(x)
+        if self.roi_guided_sampling and s < self.n_scales - 1:             # models.py:430-431
+            B_, C_, H_, W_ = x.shape
+            ew, ec = self.roi_edit_maps(s, H_, W_, x.device)
+            _lib.check(lib.sinddm_reverse_step_edit(_lib.ptr(x), _lib.ptr(eps), _lib.ptr(xt), _lib.ptr(z),
+                                                    _lib.ptr(out), C.byref(k), _lib.ptr(ew), _lib.ptr(ec), B_, C_,
+                                                    H_ * W_, _lib.stream_ptr(x.device)), "sinddm_reverse_step_edit")
+            return out
         _lib.check(lib.sinddm_reverse_step(_lib.ptr(x), _lib.ptr(eps), _lib.ptr(xt), _lib.ptr(z), _lib.ptr(out),
                                            C.byref(k), x.numel(), _lib.stream_ptr(x.device)), "sinddm_reverse_step")
         return out
 
     @torch.no_grad()
     def p_sample(self, x, t, s, clip_denoised=True, repeat_noise=False):   # models.py:449-459
-        if self.clip_guided_sampling or self.roi_guided_sampling:
-            raise NotImplementedError("CLIP / ROI guided sampling is outside the MI355X hot-path build")
+        if self.clip_guided_sampling:
+            raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
         t_host = int(t[0]) if isinstance(t, torch.Tensor) else int(t)      # the reference also reads t[0] (:331,:434)
         return self._p_sample_host_t(x, t_host, int(s), clip_denoised, repeat_noise)
 

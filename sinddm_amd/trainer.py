@@ -29,6 +29,12 @@ def image_to_tensor(img: Image.Image) -> torch.Tensor:
     return torch.from_numpy(a.transpose(2, 0, 1).copy()).to(torch.float32).div(255).mul(2).sub(1)
 
 
+def image_to_tensor_01(img: Image.Image) -> torch.Tensor:
+    """PIL RGB uint8 -> float32 CHW in [0, 1]  (torchvision ToTensor)."""
+    a = np.asarray(img.convert('RGB'), dtype=np.uint8)
+    return torch.from_numpy(a.transpose(2, 0, 1).copy()).to(torch.float32).div(255)
+
+
 def save_image(tensor: torch.Tensor, path: str, nrow: int = 8, padding: int = 2) -> None:
     """Minimal stand-in for torchvision.utils.save_image (grid of [0,1] images -> PNG). Host side,
     off the timed path."""
@@ -324,15 +330,99 @@ class MultiscaleTrainer(object):
                 save_image(final_img[b], str(unb / res_sub_folder) + f'_out_b{b}.png')
         return gathered
 
-    # ---- application modes of the reference (out of the hot-path scope) ----
-    def image2image(self, *a, **k):
-        raise NotImplementedError('harmonization / style transfer drivers are outside the MI355X hot-path build')
+    # ---- application drivers of the reference that run entirely on the hot path ----
+    @torch.no_grad()
+    def image2image(self, input_folder='', input_file='', mask='', hist_ref_path='', image_name='', start_s=1,
+                    custom_t=None, batch_size=16, scale_mul=(1, 1), device=None, use_hist=False, save_unbatched=True,
+                    auto_scale=None, mode=None, save_images=True):
+        """Harmonization / style transfer (trainer.py:287-362): re-noise the input image at scale `start_s` to
+        `custom_t[start_s]` and denoise it through the remaining scales with the trained model.  Returns the list of
+        per-scale sample batches (the reference only writes PNGs)."""
+        import os
+        from .functions import dilate_mask, match_histograms
+        device = self.device if device is None else device
+        if custom_t is None:
+            custom_t = self.ema_model.num_timesteps_ideal
+        input_img = Image.open(os.path.join(input_folder, input_file)).convert("RGB")
+        image_size = input_img.size
+        if auto_scale is not None:
+            scaler = np.sqrt((image_size[0] * image_size[1]) / auto_scale)
+            if scaler > 1:
+                image_size = (int(image_size[0] / scaler), int(image_size[1] / scaler))
+                input_img = input_img.resize(image_size, Image.LANCZOS)
+        if mode == 'harmonization':
+            mask_img = Image.open(os.path.join(input_folder, mask)).convert("RGB").resize(image_size, Image.LANCZOS)
+            mask_img = dilate_mask(image_to_tensor_01(mask_img), mode=mode)
+            mask_img = torch.from_numpy(mask_img).to(device=device, dtype=torch.float32)
+        else:
+            mask_img = 1
+        if use_hist:
+            image_name = image_name.rsplit(".", 1)[0] + '.png'
+            ref0 = Image.open(hist_ref_path + image_name).convert("RGB")
+            input_img = Image.fromarray(match_histograms(image=np.array(input_img), reference=np.array(ref0),
+                                                         channel_axis=2))
+        input_img_tensor = image_to_tensor(input_img)
+        input_size = torch.tensor(input_img_tensor.shape[1:])
+        input_img_batch = input_img_tensor.repeat(batch_size, 1, 1, 1).to(device)
 
+        final_results_folder = Path(str(self.results_folder / 'i2i_final_samples'))
+        if save_images:
+            final_results_folder.mkdir(parents=True, exist_ok=True)
+        final_img = None
+        t_string = '_'.join(str(e) for e in custom_t)
+        time = str(datetime.datetime.now()).replace(":", "_")
+        if start_s > 0:      # the starting scale has no mixing between blurry and clean images (trainer.py:326-327)
+            self.ema_model.gammas[start_s - 1].clamp_(0, 0)
+        samples_from_scales = []
+        for i in range(self.n_scales - start_s):
+            s = i + start_s
+            ds_factor = self.scale_factor ** (self.n_scales - s - 1)
+            cur_size = input_size / ds_factor
+            cur_size = (int(cur_size[0].item()), int(cur_size[1].item()))
+            src = input_img_batch if i == 0 else samples_from_scales[i - 1]
+            samples_from_scales.append(self.ema_model.sample_via_scale(batch_size, src, s=s, custom_t=custom_t[s],
+                                                                       scale_mul=scale_mul, custom_image_size=cur_size))
+            final_img = (samples_from_scales[i] + 1) * 0.5
+            if i == self.n_scales - start_s - 1:
+                denorm = ((input_img_batch + 1) * 0.5).clamp_(0.0, 1.0)
+                final_img = mask_img * final_img + (1 - mask_img) * denorm
+            if save_images:
+                name = input_file.rsplit(".", 1)[0]
+                save_image(final_img, str(final_results_folder / f'{name}_i2i_s_{start_s + i}_t_{t_string}_hist_'
+                                          f'{"on" if use_hist else "off"}_{time}.png'), nrow=4)
+        if save_images and save_unbatched:
+            unb = Path(str(self.results_folder / f'unbatched_i2i_s{start_s}_t_{t_string}_{time}'))
+            unb.mkdir(parents=True, exist_ok=True)
+            for b in range(batch_size):
+                save_image(final_img[b], os.path.join(unb, input_file + f'_out_b{b}_i2i.png'))
+        self.last_i2i_image = final_img
+        return samples_from_scales
+
+    @torch.no_grad()
+    def roi_guided_sampling(self, custom_t_list=None, target_roi=None, roi_bb_list=None, save_unbatched=False,
+                            batch_size=4, scale_mul=(1, 1), save_images=True):
+        """ROI guided generation (trainer.py:436-454): at every scale but the finest the predicted clean image is
+        pulled (eta = 0.8) towards a patch of the training image inside the given boxes; the blend runs inside the
+        fused reverse-step kernel (`sinddm_reverse_step_edit`)."""
+        from .functions import extract_patch
+        em = self.ema_model
+        em.roi_guided_sampling = True
+        em.roi_bbs = roi_bb_list
+        em.roi_target_patch = []       # (the reference appends on every call; a fresh list per call is what it means)
+        for scale in range(self.n_scales):
+            bb = [int(bb_i / np.power(self.scale_factor, self.n_scales - scale - 1)) for bb_i in target_roi]
+            em.roi_target_patch.append(extract_patch(self.data_list[scale][0][0][None, :, :, :], bb))
+        try:
+            return self.sample_scales(scale_mul=scale_mul, custom_sample=False, image_name='', batch_size=batch_size,
+                                      custom_t_list=custom_t_list,
+                                      desc=f'roi_{str(datetime.datetime.now()).replace(":", "_")}',
+                                      save_unbatched=save_unbatched, start_noise=True, save_images=save_images)
+        finally:
+            em.roi_guided_sampling = False
+
+    # ---- CLIP-driven modes of the reference (need CLIP autograd: out of the hot-path scope) ----
     def clip_sampling(self, *a, **k):
         raise NotImplementedError('CLIP guided sampling is outside the MI355X hot-path build')
 
     def clip_roi_sampling(self, *a, **k):
         raise NotImplementedError('CLIP ROI sampling is outside the MI355X hot-path build')
-
-    def roi_guided_sampling(self, *a, **k):
-        raise NotImplementedError('ROI guided sampling is outside the MI355X hot-path build')

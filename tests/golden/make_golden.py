@@ -23,6 +23,8 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   c1_pyramid.npz     the C1 balloons pyramid (uint8 images) the trainer fixtures use
   g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
   g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
+  g13_roi_i2i.npz    ROI-guided p_sample steps (roi_patch_modification) and an image2image (style-transfer path,
+                     no mask / no histogram matching: scikit-image is absent) chain, dim=32, hash noise
 """
 import contextlib
 import json
@@ -471,7 +473,82 @@ def g12(workdir):
          sizes=np.array(sizes), losses=np.array(losses), sf=np.array(sf), x_prev=x_prev)
 
 
+def g13(workdir):
+    """ROI guided p_sample steps + image2image through the reference."""
+    cfg = CONFIGS["C1"]
+    dst, fname, sizes, losses, sf, n = run_create_img_scales(cfg, os.path.join(workdir, "G13"))
+    net = ref_net(32)
+    d = make_diffusion(net, sizes, losses, sf, n, cfg["T"])
+    from PIL import Image
+    out = {}
+    # ---- ROI: two overlapping boxes (finest-scale coordinates [y, x, h, w]), target patch from the pyramid ----
+    roi_bbs = [[20, 30, 40, 36], [35, 50, 30, 30]]
+    target_roi = [10, 12, 30, 40]
+    d.roi_guided_sampling = True
+    d.roi_bbs = roi_bbs
+    d.roi_target_patch = []
+    for s in range(n):
+        img = Image.open(os.path.join(dst, f"scale_{s}", fname.rsplit(".", 1)[0] + ".png")).convert("RGB")
+        ten = torch.from_numpy(np.asarray(img).transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)[None]
+        bb = [int(b / np.power(sf, n - s - 1)) for b in target_roi]
+        d.roi_target_patch.append(rf.extract_patch(ten, bb))
+    o_noise_like = rm.noise_like
+    try:
+        for s, (H, W) in ((0, (48, 64)), (1, (67, 90))):
+            for t in (17, 0):
+                x = closed_form_tensor((2, 3, H, W), phase=0.5 + t, amp=1.1)
+                d.img_prev_upsample = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211)
+                z = hash_randn((2, 3, H, W), noise_key("step", s, t))
+                rm.noise_like = lambda shape, device, repeat=False, _z=z: _z
+                with torch.no_grad():
+                    out[f"roi_psample_s{s}_t{t}"] = d.p_sample(x, torch.full((2,), t, dtype=torch.long), s)
+    finally:
+        rm.noise_like = o_noise_like
+        d.roi_guided_sampling = False
+    out["roi_bbs"] = np.array(roi_bbs)
+    out["target_roi"] = np.array(target_roi)
+    # ---- image2image, style-transfer configuration of main.py:296-322 without histogram matching ----
+    d2 = make_diffusion(ref_net(32), sizes, losses, sf, n, cfg["T"])
+    tr = rt.MultiscaleTrainer(d2, folder=dst, n_scales=n, scale_factor=sf, image_sizes=sizes, train_batch_size=2,
+                              train_lr=1e-3, train_num_steps=1, gradient_accumulate_every=1, ema_decay=0.995,
+                              fp16=False, step_start_ema=1, update_ema_every=1, save_and_sample_every=10 ** 9,
+                              avg_window=1, sched_milestones=[100], results_folder=tempfile.mkdtemp(), device=DEV)
+    i2i = os.path.join(workdir, "G13", "i2i")
+    os.makedirs(i2i, exist_ok=True)
+    # the input: the training image with swapped channels and a gradient (any RGB image of the finest size)
+    base = np.asarray(Image.open(os.path.join(dst, f"scale_{n - 1}", fname.rsplit(".", 1)[0] + ".png")).convert("RGB"))
+    inp = base[:, ::-1, ::-1].copy()
+    inp[:, :, 0] = (inp[:, :, 0].astype(np.int32) * 3 // 4 + np.arange(inp.shape[1])[None, :] // 2).clip(0, 255)
+    Image.fromarray(inp.astype(np.uint8)).save(os.path.join(i2i, "input.png"))
+    start_s, start_t = n - 1, 7
+    custom_t = [0] * (n - 1) + [start_t]
+    feeder = NoiseFeeder([("renoise", start_s, 0)] + [("step", start_s, t) for t in reversed(range(start_t))])
+    tr.ema_model.reblurring = True
+    saved = []
+    o_save = rt.utils.save_image
+    rt.utils.save_image = lambda img, *a, **k: saved.append(img.detach().clone())
+    try:
+        with patched_noise(feeder):
+            tr.image2image(input_folder=i2i, input_file="input.png", mask="", hist_ref_path="", batch_size=2,
+                           image_name=fname, start_s=start_s, custom_t=custom_t, scale_mul=(1, 1), device=DEV,
+                           use_hist=False, save_unbatched=False, auto_scale=50000, mode="style_transfer")
+    finally:
+        rt.utils.save_image = o_save
+    out["i2i_input"] = inp.astype(np.uint8)
+    out["i2i_final"] = saved[-1]
+    out["i2i_custom_t"] = np.array(custom_t)
+    out["i2i_gamma_row_after"] = tr.ema_model.gammas[start_s - 1].detach().clone()
+    save("g13_roi_i2i.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":
+        workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
+        try:
+            g13(workdir)
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
         try:
@@ -491,6 +568,7 @@ def main():
         g9(meta)
         g10(meta, workdir)
         g12(workdir)
+        g13(workdir)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

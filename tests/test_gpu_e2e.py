@@ -141,3 +141,121 @@ def test_load_reference_checkpoint(golden, tmp_path):
     em.noise_fn = lambda kind, shape, s, t, device: z
     y = em.p_sample(hash_randn((2, 3, H, W), 1202).to(DEV), torch.full((2,), 17, dtype=torch.long, device=DEV), 1)
     assert rel_l2(y.cpu(), g["x_prev"]) < 1e-5
+
+
+def _roi_patches(golden, meta, target_roi):
+    pyr = golden("c1_pyramid.npz")
+    n, sf = meta["n_scales"], meta["scale_factor"]
+    out = []
+    for s in range(n):
+        ten = torch.from_numpy(pyr[f"scale_{s}"].transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)[None]
+        y, x, h, w = [int(b / np.power(sf, n - s - 1)) for b in target_roi]
+        out.append(ten[:, :, y:y + h, x:x + w])
+    return out
+
+
+def test_roi_guided_psample_golden(golden, tmp_path):
+    """G13: the fused reverse step with ROI guidance (sinddm_reverse_step_edit) vs the reference's p_sample with
+    roi_guided_sampling, s=0 (DDPM posterior) and s=1 (re-blur branch), t>0 and t=0."""
+    from sinddm_amd.synth import closed_form_tensor
+    g = golden("g13_roi_i2i.npz")
+    tr, meta = _trainer(golden, tmp_path, T=100)
+    d = tr.ema_model
+    d.roi_guided_sampling = True
+    d.roi_bbs = [list(map(int, bb)) for bb in g["roi_bbs"]]
+    d.roi_target_patch = [p.to(DEV) for p in _roi_patches(golden, meta, g["target_roi"])]
+    for s, (H, W) in ((0, (48, 64)), (1, (67, 90))):
+        for t in (17, 0):
+            x = closed_form_tensor((2, 3, H, W), phase=0.5 + t, amp=1.1).to(DEV)
+            d.img_prev_upsample = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211).to(DEV)
+            d.noise_fn = lambda kind, shape, s_, t_, dev: hash_randn(shape, noise_key("step", s_, t_)).to(dev)
+            y = d.p_sample(x, torch.full((2,), t, dtype=torch.long, device=DEV), s)
+            assert rel_l2(y.cpu(), g[f"roi_psample_s{s}_t{t}"]) < 1e-5, (s, t)
+    # the finest scale is never guided (models.py:430)
+    s = 2
+    H, W = meta["image_sizes_hw"][s]
+    x = closed_form_tensor((1, 3, H, W), phase=0.3, amp=1.0).to(DEV)
+    d.img_prev_upsample = closed_form_tensor((1, 3, H, W), phase=2.5, amp=0.8, freq=0.211).to(DEV)
+    y_on = d.p_sample(x, torch.full((1,), 5, dtype=torch.long, device=DEV), s)
+    d.roi_guided_sampling = False
+    y_off = d.p_sample(x, torch.full((1,), 5, dtype=torch.long, device=DEV), s)
+    assert torch.equal(y_on, y_off)
+
+
+def test_image2image_golden(golden, tmp_path):
+    """G13: MultiscaleTrainer.image2image (style-transfer configuration of main.py, no histogram matching) vs the
+    reference run with the same hash noise."""
+    g = golden("g13_roi_i2i.npz")
+    tr, meta = _trainer(golden, tmp_path, T=100)
+    i2i = tmp_path / "i2i"
+    i2i.mkdir()
+    Image.fromarray(g["i2i_input"]).save(str(i2i / "input.png"))
+    d = tr.ema_model
+    d.noise_fn = lambda kind, shape, s, t, dev: hash_randn(shape, noise_key(kind, s, t)).to(dev)
+    n = meta["n_scales"]
+    outs = tr.image2image(input_folder=str(i2i), input_file="input.png", mask="", hist_ref_path="", batch_size=2,
+                          image_name="balloons.png", start_s=n - 1, custom_t=[int(v) for v in g["i2i_custom_t"]],
+                          scale_mul=(1, 1), device=DEV, use_hist=False, save_unbatched=True, auto_scale=50000,
+                          mode="style_transfer")
+    assert len(outs) == 1
+    assert float(d.gammas[n - 2].abs().max()) == 0.0                     # trainer.py:326-327
+    assert rel_l2(tr.last_i2i_image.cpu(), g["i2i_final"]) < 1e-5
+    pngs = [f for _, _, fs in os.walk(tmp_path / "res") for f in fs if "i2i" in f and f.endswith(".png")]
+    assert len(pngs) >= 3
+
+
+def test_roi_guided_sampling_chain_vs_oracle(golden, tmp_path):
+    """MultiscaleTrainer.roi_guided_sampling (trainer.py:436-454) over all scales == the oracle chain with the ROI
+    blend at every scale but the finest, T=20."""
+    tr, meta = _trainer(golden, tmp_path)
+    d = tr.ema_model
+    d.noise_fn = lambda kind, shape, s, t, dev: hash_randn(shape, noise_key(kind, s, t)).to(dev)
+    bbs, target = [[20, 30, 40, 36], [35, 50, 30, 30]], [10, 12, 30, 40]
+    outs = tr.roi_guided_sampling(custom_t_list=d.num_timesteps_ideal[1:], target_roi=target, roi_bb_list=bbs,
+                                  save_unbatched=False, batch_size=2, scale_mul=(1, 1), save_images=False)
+    assert d.roi_guided_sampling is False
+    sched = O.make_schedule(20, meta["n_scales"], meta["rescale_losses"], 1, train_full_t=True)
+    sizes = [tuple(s) for s in meta["image_sizes_hw"]]
+
+    class Noise(dict):
+        def __missing__(self, k):
+            kind, s = k[0], k[1]
+            t = k[2] if len(k) > 2 else 0
+            return hash_randn((2, 3) + sizes[s], noise_key(kind, s, t))
+
+    roi = dict(bbs=bbs, target_patch=_roi_patches(golden, meta, target), scale_factor=meta["scale_factor"])
+    with torch.no_grad():
+        ref = O.sample_chain(sched, closed_form_state_dict(32), sizes, Noise(), 2, roi=roi)
+        plain = O.sample_chain(sched, closed_form_state_dict(32), sizes, Noise(), 2)
+    for i, (a, b) in enumerate(zip(outs, ref)):
+        assert rel_l2(a.cpu(), b) < 1e-4, i
+    assert rel_l2(ref[0], plain[0]) > 1e-2            # the guidance is not a no-op
+
+
+def test_harmonization_mask_blend(golden, tmp_path):
+    """image2image(mode='harmonization'): far outside the (dilated, blurred) mask the result is the input image,
+    inside it is the model's sample (trainer.py:299-305,352-355)."""
+    g = golden("g13_roi_i2i.npz")
+    tr, meta = _trainer(golden, tmp_path, T=100)
+    i2i = tmp_path / "i2i"
+    i2i.mkdir()
+    inp = g["i2i_input"]
+    Image.fromarray(inp).save(str(i2i / "input.png"))
+    H, W = inp.shape[:2]
+    mask = np.zeros((H, W, 3), dtype=np.uint8)
+    mask[30:50, 40:70] = 255
+    Image.fromarray(mask).save(str(i2i / "mask.png"))
+    n = meta["n_scales"]
+    outs = tr.image2image(input_folder=str(i2i), input_file="input.png", mask="mask.png", hist_ref_path="", batch_size=2,
+                          image_name="balloons.png", start_s=n - 1, custom_t=[0] * (n - 1) + [5], scale_mul=(1, 1),
+                          device=DEV, use_hist=False, save_unbatched=False, auto_scale=50000, mode="harmonization",
+                          save_images=False)
+    final = tr.last_i2i_image.cpu()
+    sample = ((outs[-1] + 1) * 0.5).cpu()
+    src = torch.from_numpy(inp.transpose(2, 0, 1).copy()).float().div(255)[None].repeat(2, 1, 1, 1)
+    assert torch.allclose(final[:, :, :5, :5], src[:, :, :5, :5], atol=1e-6)             # mask == 0
+    assert torch.allclose(final[:, :, 38:42, 53:57], sample[:, :, 38:42, 53:57], atol=2e-3)   # mask ~ 1
+    from sinddm_amd.functions import dilate_mask
+    m = torch.from_numpy(dilate_mask(torch.from_numpy(mask.transpose(2, 0, 1).copy()).float().div(255), "harmonization")).float()
+    assert torch.allclose(final, m * sample + (1 - m) * src, atol=2e-6)
+    assert torch.isfinite(final).all()

@@ -183,3 +183,69 @@ def test_helpers():
     a = torch.arange(10.0)
     assert F.extract(a, torch.tensor([2, 7]), (2, 3, 4, 4)).shape == (2, 1, 1, 1)
     assert np.array_equal(F.cosine_beta_schedule(100), O.cosine_beta_schedule(100))
+
+
+def test_roi_edit_maps_compose_sequential_blends():
+    """roi_edit_maps folds the reference's sequential box blends (models.py:291-298) into one affine map."""
+    from oracle import sinddm_oracle as O
+    meta = dict(n_scales=3, scale_factor=1.4, sizes=[(64, 48), (90, 67), (126, 94)], T=100, rescale_losses=[1.0, 0.7])
+    d = _diffusion(meta)
+    g = torch.Generator().manual_seed(3)
+    bbs = [[20, 30, 40, 36], [35, 50, 30, 30], [0, 0, 10, 10]]            # two overlap
+    d.roi_bbs = bbs
+    d.roi_target_patch = [torch.randn(1, 3, 9 + s, 11 + s, generator=g) for s in range(3)]
+    for s, (H, W) in ((0, (48, 64)), (1, (67, 90))):
+        x = torch.randn(2, 3, H, W, generator=g)
+        w, c = d.roi_edit_maps(s, H, W, "cpu")
+        want = O.roi_patch_modification(x, bbs, d.roi_target_patch[s], 1.4, 3, s)
+        got = w[None, None] * x + c[None]
+        assert torch.allclose(got, want, atol=1e-6)
+        assert torch.equal(d.roi_patch_modification(x.clone(), scale=s), got)
+        assert d.roi_edit_maps(s, H, W, "cpu")[0] is w                     # cached
+
+
+def test_match_histograms_properties():
+    from sinddm_amd.functions import match_histograms
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, size=(40, 50, 3), dtype=np.uint8)
+    ref = (rng.integers(0, 128, size=(30, 20, 3)) + 64).astype(np.uint8)
+    out = match_histograms(image=src, reference=ref, channel_axis=2)
+    assert out.dtype == np.uint8 and out.shape == src.shape
+    assert np.array_equal(match_histograms(src, src), src)                 # matching to itself is the identity
+    for ch in range(3):
+        assert out[..., ch].min() >= ref[..., ch].min() and out[..., ch].max() <= ref[..., ch].max()
+        # monotone in the source level
+        lv = [out[..., ch][src[..., ch] == v].max() for v in np.unique(src[..., ch])]
+        assert all(a <= b for a, b in zip(lv, lv[1:]))
+        assert abs(float(np.median(out[..., ch])) - float(np.median(ref[..., ch]))) <= 2
+    with pytest.raises(ValueError):
+        match_histograms(src, ref[..., :2])
+
+
+def test_dilate_mask_properties():
+    from sinddm_amd.functions import dilate_mask
+    m = torch.zeros(3, 80, 100)
+    m[:, 30:40, 45:55] = 1.0
+    out = dilate_mask(m, mode="harmonization")
+    assert out.shape == (1, 1, 80, 100) and out.dtype == np.float64
+    assert out.min() == 0.0 and out.max() == 1.0
+    assert out[0, 0, 35, 50] == 1.0                                         # centre of the blob stays saturated
+    assert out[0, 0, 35, 50 + 10] > 0.5                                     # inside the 7-pixel dilation
+    assert out[0, 0, 35, 50 + 5 + 7 + 20] < 1e-3                            # beyond dilation + 4 sigma
+    assert out[0, 0, 0, 0] == 0.0
+    big = dilate_mask(m, mode="editing")
+    assert (big > 0.5).sum() > (out > 0.5).sum()
+    with pytest.raises(ValueError):
+        dilate_mask(m, mode="other")
+
+
+def test_main_parser_modes():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("sinddm_main", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "main.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.build_parser().parse_args(["--mode", "roi", "--roi_target", "1", "2", "3", "4", "--roi_bbs", "5", "6", "7", "8", "9", "10", "11", "12"])
+    assert a.roi_target == [1, 2, 3, 4] and len(a.roi_bbs) == 8
+    a = mod.build_parser().parse_args(["--mode", "harmonization"])
+    assert a.start_t_harm == 5 and a.start_t_style == 15 and a.harm_mask == "seascape_mask_dragon.png"

@@ -187,3 +187,62 @@ def test_g12_reference_checkpoint(golden):
     xt, xtil, z = hash_randn((2, 3, H, W), 1202), hash_randn((2, 3, H, W), 1203).clamp(-1, 1), hash_randn((2, 3, H, W), 1204)
     y = O.p_sample(sched, sd, xt, 17, 1, z, xtil)
     assert rel_l2(y, g["x_prev"]) < 5e-6
+
+
+def _roi_setup(golden):
+    g = golden("g13_roi_i2i.npz")
+    meta = golden("g11_img_scales.json")["C1"]
+    pyr = golden("c1_pyramid.npz")
+    n, sf = meta["n_scales"], meta["scale_factor"]
+    patches = []
+    for s in range(n):
+        ten = torch.from_numpy(pyr[f"scale_{s}"].transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)[None]
+        y, x, h, w = [int(b / np.power(sf, n - s - 1)) for b in g["target_roi"]]
+        patches.append(ten[:, :, y:y + h, x:x + w])
+    return g, meta, patches
+
+
+def test_g13_roi_guided_psample(golden):
+    """G13: p_sample with roi_guided_sampling (roi_patch_modification at models.py:430-431), s=0 and s=1."""
+    from sinddm_amd.synth import closed_form_state_dict, closed_form_tensor, hash_randn, noise_key
+    g, meta, patches = _roi_setup(golden)
+    n, sf = meta["n_scales"], meta["scale_factor"]
+    sched = O.make_schedule(meta["T"], n, meta["rescale_losses"], loss_factor=1, train_full_t=True)
+    sd = closed_form_state_dict(32)
+    bbs = [list(map(int, bb)) for bb in g["roi_bbs"]]
+    for s, (H, W) in ((0, (48, 64)), (1, (67, 90))):
+        for t in (17, 0):
+            x = closed_form_tensor((2, 3, H, W), phase=0.5 + t, amp=1.1)
+            xtil = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211)
+            z = hash_randn((2, 3, H, W), noise_key("step", s, t))
+            edit = lambda xr, s=s: O.roi_patch_modification(xr, bbs, patches[s], sf, n, s)
+            y = O.p_sample(sched, sd, x, t, s, z, xtil, x_recon_edit=edit)
+            assert rel_l2(y, g[f"roi_psample_s{s}_t{t}"]) < 5e-6, (s, t)
+            # and the guidance really changes the step
+            assert rel_l2(O.p_sample(sched, sd, x, t, s, z, xtil), g[f"roi_psample_s{s}_t{t}"]) > 1e-3
+
+
+def test_g13_image2image_chain(golden):
+    """G13: image2image (style-transfer configuration, trainer.py:287-362): gamma row of the start scale zeroed,
+    input re-noised to custom_t[start_s] and denoised at the finest scale."""
+    from sinddm_amd.synth import closed_form_state_dict, hash_randn, noise_key
+    g, meta, _ = _roi_setup(golden)
+    n = meta["n_scales"]
+    sched = O.make_schedule(meta["T"], n, meta["rescale_losses"], loss_factor=1, train_full_t=True)
+    s0 = n - 1
+    sched = dict(sched)
+    gam = torch.as_tensor(np.asarray(sched["gammas"])).clone()
+    gam[s0 - 1] = gam[s0 - 1].clamp(0, 0)                       # trainer.py:326-327
+    sched["gammas"] = gam
+    assert np.array_equal(g["i2i_gamma_row_after"], np.zeros_like(g["i2i_gamma_row_after"]))
+    sd = closed_form_state_dict(32)
+    inp = torch.from_numpy(g["i2i_input"].transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)
+    batch = inp[None].repeat(2, 1, 1, 1)
+    total_t = int(g["i2i_custom_t"][s0])
+    H, W = inp.shape[1:]
+    up = O.bilinear_upsample(batch, (H, W))
+    assert torch.equal(up, batch)                                # same-size bilinear resize is the identity
+    img = O.q_sample(sched, up, torch.full((2,), total_t, dtype=torch.long), hash_randn((2, 3, H, W), noise_key("renoise", s0, 0)))
+    for t in reversed(range(total_t)):
+        img = O.p_sample(sched, sd, img, t, s0, hash_randn((2, 3, H, W), noise_key("step", s0, t)), up)
+    assert rel_l2((img + 1) * 0.5, g["i2i_final"]) < 1e-5
