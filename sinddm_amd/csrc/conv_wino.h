@@ -24,6 +24,13 @@
 
 namespace sinddm {
 
+// Compile-time timing ablations of the Winograd kernel (-DSINDDM_WINO_ABL=bits; results are WRONG, never ship):
+//   1 no LDS reads / V transform   2 weights loaded once   4 raw-tile DMA only for the first chunk
+//   8 no chunk barrier             16 no epilogue
+#ifndef SINDDM_WINO_ABL
+#define SINDDM_WINO_ABL 0
+#endif
+
 constexpr int WN_THREADS = 1024;
 constexpr int WN_KC = 16;                      // input channels per chunk (4 k-steps)
 constexpr int WN_TW = 32;
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     // (chunk c, k-step ks) -> global k-step index; nothing is loaded (or multiplied) past the last real one
     auto load_w = [&](int slot, int cb, int c, int ks) {
         const int gk = c * NKS + ks;
+        if ((SINDDM_WINO_ABL & 2) && gk >= 2) return;
         if (gk >= nks_total) return;
         const int so = ((cb * nch16 + (gk >> 2)) * 16 + xi) * (4 * MT * 64 * 4) + (gk & 3) * (MT * 64 * 4);
 #pragma unroll
@@ -182,9 +190,10 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
                 const bool live = (CPC == 1) || (c * NKS + ks < nks_total);
 #pragma unroll
                 for (int nt = 0; nt < NTR; ++nt) {
-                    const float bv = s00 * r4[0] + s01 * r4[1] + s10 * r4[2] + s11 * r4[3];
+                    const float bv = (SINDDM_WINO_ABL & 1) ? (float)(ks + nt) * s00
+                                                           : s00 * r4[0] + s01 * r4[1] + s10 * r4[2] + s11 * r4[3];
                     // next group (same k-step next tile-row, or first tile-row of the next k-step)
-                    if (nt + 1 < NTR || ks + 1 < NKS) {
+                    if (!(SINDDM_WINO_ABL & 1) && (nt + 1 < NTR || ks + 1 < NKS)) {
                         const int nks = (nt + 1 < NTR) ? ks : ks + 1;
                         const int nnt = (nt + 1 < NTR) ? nt + 1 : 0;
                         const float* q = cur + nks * 4 * WN_PS + nnt * 2 * WN_RS;
@@ -197,13 +206,13 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
                     }
                 }
                 if (ks < NKS - 2) load_w(ks & 1, it.cb, c, ks + 2);
-                if (ks == 1 && more) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
+                if (ks == 1 && more && !(SINDDM_WINO_ABL & 4)) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);
                 if (ks == NKS - 2 && more) load_w(0, it.cb, c + 1, 0);
             }
             // pin the schedule here: left alone, the compiler sinks the last k-step's MFMAs below the barrier and
             // rotates the accumulators through spare registers (3.5% slower, measured A/B on one box)
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if (!(SINDDM_WINO_ABL & 8)) __syncthreads();
         }
 
         // next work item: start its first raw tile and weight registers now, so that they arrive while this
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
             issue(nx, 0, smem);
         }
 
-        {
+        if (!(SINDDM_WINO_ABL & 16)) {
             // ---- output transform + epilogue, MPP 16-channel M tiles per pass ----
 #pragma unroll
             for (int m0 = 0; m0 < MT; m0 += MPP) {
@@ -292,6 +301,13 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
                 }
                 __syncthreads();
             }
+        } else {
+            float sink = 0.f;                                   // keep every accumulator chain alive
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTR; ++nt) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+            if (sink == 123.456f) p.out[tid] = sink;
         }
         if (!have_next) break;
         it = nx;
