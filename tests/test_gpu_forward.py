@@ -54,7 +54,8 @@ def test_net_forward_golden(golden, dim, H, W):
 
 
 @pytest.mark.parametrize("dim,B,H,W", [(160, 1, 5, 7), (160, 3, 8, 32), (160, 2, 9, 33), (160, 1, 48, 64),
-                                       (32, 2, 17, 100), (16, 1, 33, 31), (160, 2, 94, 126)])
+                                       (32, 2, 17, 100), (16, 1, 33, 31), (160, 2, 94, 126),
+                                       (48, 2, 19, 35), (64, 1, 13, 66), (80, 2, 14, 40), (96, 1, 20, 33)])
 def test_net_forward_vs_oracle_edges(dim, B, H, W):
     """Ragged / tiny / tile-boundary sizes against the oracle; host-t and device-t paths agree."""
     net = _net(dim)
@@ -181,3 +182,19 @@ def test_sampler_properties_full_size(golden):
     y1 = d._p_sample_host_t(x[:1].contiguous(), 100, s)
     assert torch.equal(y1, y4[:1])
     assert torch.isfinite(y4).all()
+
+
+def test_large_batch_index_range():
+    """C3 finest scale (B=64, 411x512): one 160-channel tensor has 2.15e9 elements > 2^31 -- the tail samples of the
+    big batch must equal the same samples run alone (32-bit index overflow would corrupt exactly those)."""
+    net = _net(160)
+    B, H, W = 64, 411, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(B, 3, H, W, device=DEV, generator=g)
+    t = torch.randint(0, 1000, (B,), device=DEV, generator=g)
+    with torch.no_grad():
+        y = net(x, t, scale=5)
+        y_tail = net(x[-2:].contiguous(), t[-2:].contiguous(), scale=5)
+        y_head = net(x[:2].contiguous(), t[:2].contiguous(), scale=5)
+    assert torch.isfinite(y).all()
+    assert torch.equal(y[-2:], y_tail) and torch.equal(y[:2], y_head)

@@ -97,7 +97,8 @@ def test_p_losses_grads_golden(golden, s):
     print("worst rel-l2 grad error", worst)
 
 
-@pytest.mark.parametrize("dim,B,H,W", [(160, 2, 21, 37), (160, 1, 40, 70), (32, 3, 9, 33), (16, 1, 5, 7)])
+@pytest.mark.parametrize("dim,B,H,W", [(160, 2, 21, 37), (160, 1, 40, 70), (32, 3, 9, 33), (16, 1, 5, 7),
+                                       (48, 2, 11, 35), (80, 2, 14, 40), (96, 1, 9, 33)])
 def test_net_backward_vs_oracle_autograd(dim, B, H, W):
     """Parameter gradients AND input gradient vs torch autograd through the CPU oracle (ragged sizes)."""
     from sinddm_amd.models import SinDDMNet
