@@ -7,6 +7,9 @@
 // ([coblk][8-ch chunk][ci][CO_LDS]: two consecutive 8-channel chunks form one 16-channel chunk), inputs as one
 // 256-byte wave instruction per (channel, 64-pixel segment) with bounds-check zero fill.  HBM-bound
 // (4*(C_in + C_out) B per pixel); LDS strides == 16 (mod 32) keep both operand reads conflict-free.
+// MFMA column l16 of n-tile nt is pixel 4*l16 + nt of the wave's 64-pixel segment, so the B operand of a k-step is
+// ONE ds_read_b128 and a lane owns 4 consecutive pixels per (channel) in the epilogue: 16-byte stores / residual
+// loads instead of four 4-byte ones (the epilogue is store-issue bound).
 #pragma once
 #include "conv_mfma.h"
 
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int aBase = kq * CO_LDS + l16;
-    const int bBase = W_FLOATS + kq * C1_PS + wave * 64 + l16;
+    const int bBase = W_FLOATS + kq * C1_PS + wave * 64 + l16 * 4;
     issue(0, smem);
     __syncthreads();
     for (int c = 0; c < nch; ++c) {
@@ -75,11 +78,10 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
 #pragma unroll
         for (int ks = 0; ks < C1_KC / 4; ++ks) {
-            float a[MT], bv[4];
+            float a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) a[mt] = cur[aBase + ks * 4 * CO_LDS + mt * 16];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = cur[bBase + ks * 4 * C1_PS + nt * 16];
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(cur + bBase + ks * 4 * C1_PS);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -89,25 +91,40 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
         __syncthreads();
     }
 
+    const int px0 = p0 + wave * 64 + l16 * 4;          // this lane's 4 consecutive pixels
+    const bool full = px0 + 3 < HW;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = mt * 16 + kq * 4 + r;
             const int co = cb * (MT * 16) + col;
-            if (co >= p.Cout) continue;
+            if (co >= p.Cout || px0 >= HW) continue;
             const float bvs = p.bias ? p.bias[cb * (MT * 16) + col] : 0.0f;
-            const size_t cbase = ((size_t)b * p.Cout + co) * HW;
+            const size_t o = ((size_t)b * p.Cout + co) * HW + px0;
+            f32x4 v{acc[mt][0][r] + bvs, acc[mt][1][r] + bvs, acc[mt][2][r] + bvs, acc[mt][3][r] + bvs};
+            if (full) {
+                // 16-byte accesses at 4-byte alignment (H*W may be odd): fine for global memory on gfx9
+                if (p.act == 1) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int px = p0 + wave * 64 + nt * 16 + l16;
-                if (px < HW) {
-                    const size_t o = cbase + px;
-                    float v = acc[mt][nt][r] + bvs;
-                    if (p.act == 1) v = gelu_erf(v);
-                    else if (p.act == 2) v *= gelu_erf_grad(p.aux[o]);
-                    if (p.resid) v += p.resid[o];
-                    p.out[o] = v;
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if (p.act == 2) {
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(p.aux + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+                }
+                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                *reinterpret_cast<f32x4*>(p.out + o) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (px0 + j < HW) {
+                        float w = v[j];
+                        if (p.act == 1) w = gelu_erf(w);
+                        else if (p.act == 2) w *= gelu_erf_grad(p.aux[o + j]);
+                        if (p.resid) w += p.resid[o + j];
+                        p.out[o + j] = w;
+                    }
                 }
             }
         }
