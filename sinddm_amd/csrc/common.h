@@ -7,6 +7,7 @@
 namespace sinddm {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 #define SINDDM_LAUNCH_CHECK()                          \
     do {                                               \
