@@ -31,6 +31,11 @@ namespace sinddm {
 #define SINDDM_WINO_ABL 0
 #endif
 
+#ifdef SINDDM_WINO_TIMING
+// per-wave s_memtime stamps of the first work items of workgroup 0 (debug builds only; tools/wino_timing.py)
+__device__ unsigned long long g_wino_dbg[2 * 16 * 16 * 4];
+#endif
+
 constexpr int WN_THREADS = 1024;
 constexpr int WN_KC = 16;                      // input channels per chunk (4 k-steps)
 constexpr int WN_TW = 32;
@@ -161,6 +166,9 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     const int tr = lane >> 4, tc = lane & 15;   // epilogue role of a lane: 2x2 tile (tile-row, tile-col)
     const int lt = lane < WG::NTILES ? lane : 0;
 
+#ifdef SINDDM_WINO_TIMING
+    int dbg_item = 0;
+#endif
     for (;;) {
         f32x4 acc[MT][NTR];
 #pragma unroll
@@ -175,6 +183,10 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
         //   after k-step NKS-2      : load k-step 0 of the next chunk
         //   k-step NKS-1, barrier, then load k-step 1 of the next chunk -- needed one k-step later
         for (int c = 0; c < nch; ++c) {
+#ifdef SINDDM_WINO_TIMING
+            const bool dbg = blockIdx.x == 8 && dbg_item < 2 && c < 16 && lane == 0;
+            if (dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 0] = __builtin_amdgcn_s_memtime();
+#endif
             const float* cur = smem + (c & 1) * WN_IN_LIN;
             const bool more = c + 1 < nch;
             if (c > 0) load_w(1, it.cb, c, 1);
@@ -212,8 +224,17 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
             // pin the schedule here: left alone, the compiler sinks the last k-step's MFMAs below the barrier and
             // rotates the accumulators through spare registers (3.5% slower, measured A/B on one box)
             __builtin_amdgcn_sched_barrier(0);
+#ifdef SINDDM_WINO_TIMING
+            if (dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
             if (!(SINDDM_WINO_ABL & 8)) __syncthreads();
+#ifdef SINDDM_WINO_TIMING
+            if (dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 2] = __builtin_amdgcn_s_memtime();
+#endif
         }
+#ifdef SINDDM_WINO_TIMING
+        ++dbg_item;
+#endif
 
         // next work item: start its first raw tile and weight registers now, so that they arrive while this
         // item's epilogue runs (raw buffer 0 is free: every wave passed the last chunk barrier)

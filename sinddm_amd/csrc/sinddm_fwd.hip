@@ -619,6 +619,12 @@ int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_
     return 0;
 }
 
+#ifdef SINDDM_WINO_TIMING
+int sinddm_debug_wino_timing(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wino_dbg), sizeof(unsigned long long) * n);
+}
+#endif
+
 int sinddm_prof_begin(void) {
     ConvProfiler& p = conv_profiler();
     p.on = true;
