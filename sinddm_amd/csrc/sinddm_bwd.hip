@@ -6,6 +6,7 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "internal.h"
+#include "wgrad_wino.h"
 
 namespace sinddm {
 
@@ -394,6 +395,34 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
     a.tilesX = (W + WG_TW - 1) / WG_TW;
     a.tilesY = (H + WG_TH - 1) / WG_TH;
     a.ntiles = B * a.tilesX * a.tilesY;
+    static const int ww = getenv("SINDDM_WGRAD_WINO") ? atoi(getenv("SINDDM_WGRAD_WINO")) : 1;
+    if (taps == 9 && Cout % WW_CO == 0 && Cin >= 16 && ww && scr) {
+        // Winograd-domain weight gradient (2.25x fewer MFMAs); always through the [co][tap][ci] staging slab
+        if ((size_t)WW_CO * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
+        WwArgs w{};
+        w.dout = dout; w.in = in; w.gw = scr; w.gb = gb;
+        w.B = B; w.H = H; w.W = W; w.Cin = Cin; w.Cout = Cout;
+        w.coblks = Cout / WW_CO;
+        w.ciblks = (Cin + WW_CI - 1) / WW_CI;
+        w.tilesX = (W + WW_TW - 1) / WW_TW;
+        w.tilesY = (H + WW_TH - 1) / WW_TH;
+        w.ntiles = B * w.tilesX * w.tilesY;
+        const int pairs = w.coblks * w.ciblks;
+        int S = (device_cu_count() / pairs) / 8 * 8;
+        if (S < 8) S = 8;
+        const int cap = (w.ntiles + 7) / 8 * 8;
+        if (S > cap) S = cap;
+        w.S = S;
+        const int n = Cout * Cin * 9;
+        hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        constexpr size_t lds = (size_t)2 * WW_BUF * sizeof(float);
+        hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(pairs * S)), dim3(WW_THREADS), lds, st, w);
+        SINDDM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wgrad_unstage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scr, gw, Cin, n);
+        SINDDM_LAUNCH_CHECK();
+        return 0;
+    }
     if (taps == 9 && Cout % W3_C == 0 && w3) {
         // one workgroup per CU; the largest per-sample channel slab must stay below the buffer OOB marker
         if ((size_t)W3_C * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;

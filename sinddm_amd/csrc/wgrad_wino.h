@@ -1,0 +1,254 @@
+// 3x3 weight gradient in the Winograd F(2x2,3x3) domain on the fp32 matrix cores.
+//
+//   forward:   Y_tile = A^T [ sum_ci U_xi(co,ci) (.) V_xi(ci,tile) ] A,   U = G g G^T,  V = B^T d B
+//   gradient:  dU_xi(co,ci) = sum_tiles dM_xi(co,tile) * V_xi(ci,tile),   dM = A dY A^T (4x4 from the 2x2 dY block)
+//              dg = G^T dU G
+// 16 frequency GEMMs with K = number of 2x2 tiles = pixels/4 instead of 9 GEMMs with K = pixels: 2.25x fewer MFMAs
+// than the direct weight gradient (autograd of the convs of reference SinDDM/models.py:63,65 via functions.py:97-102).
+//
+// Mapping: a 16-wave workgroup per CU owns an (80 co x 48 ci) slab and a strided subset of the 2x32-pixel tiles
+// (16 tiles = 4 k-steps of v_mfma_f32_16x16x4_f32 each); WAVE xi owns frequency xi: 5x3 accumulator tiles.
+// Both operands are built on the fly from LDS: dM_xi from the dY tile (<= 4 signed reads), V_xi from the input
+// halo tile (4 signed reads), like the forward kernel's V.  The tiles are LDS-DMA'd with the pixel columns
+// DE-INTERLEAVED (a row is stored [even columns | odd columns]; the gather happens in the per-lane global offsets),
+// so the four pixels of tile column c sit at index c of their half-row and the k-lanes read consecutive floats:
+// plane strides == 2 (mod 32) keep every operand read bank-conflict free.
+// Epilogue (once per workgroup): the 16 frequencies of an M tile meet in LDS, thread (co, ci) applies G^T . G and
+// adds its 9 taps into the [co][tap][ci] staging slab with coalesced atomics; the bias gradient falls out of
+// frequency (1,1), whose dM is the plain sum of the 2x2 block.
+#pragma once
+#include "common.h"
+
+namespace sinddm {
+
+constexpr int WW_THREADS = 1024;
+constexpr int WW_CO = 80, WW_CI = 48;
+constexpr int WW_TW = 32, WW_TH = 2;                 // pixel tile = one row of 16 2x2 tiles
+constexpr int WW_PSO = 2 * 32 + 2;                   // dY plane: [2 rows][even 16 | odd 16] + pad      (== 2 mod 32)
+constexpr int WW_XR = 34;                            // input row incl. halo: [even 17 | odd 17]
+constexpr int WW_PSI = 162;                          // input plane: 4 rows x 34 = 136 -> 162            (== 2 mod 32)
+constexpr int WW_BUF = WW_CO * WW_PSO + WW_CI * WW_PSI;   // floats per stage (13056 = 51 KB)
+constexpr int WW_ESTRIDE = WW_CI + 1;                // epilogue exchange [xi][16 co][48 ci + 1]
+
+struct WwArgs {
+    const float* dout;   // [B][Cout][H][W]
+    const float* in;     // [B][Cin][H][W]
+    float* gw;           // staging slab [Cout][9][Cin]  (+=, atomics)
+    float* gb;           // [Cout] (+=) or nullptr
+    int B, H, W, Cin, Cout;
+    int coblks, ciblks, S;
+    int tilesX, tilesY, ntiles;
+};
+
+__global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int pairs = p.coblks * p.ciblks;
+    const int q = slot % pairs;
+    const int s = (slot / pairs) * 8 + xcd;          // pixel-split index; same-split slabs share an XCD/L2
+    const int cb = q / p.ciblks, cib = q - cb * p.ciblks;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave = Winograd frequency (i, j)
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int tpi = p.tilesX * p.tilesY;
+    const int ci0 = cib * WW_CI;
+    const int nci = min(WW_CI, p.Cin - ci0);
+    const int nnt = (nci + 15) >> 4;                 // 16-channel ci tiles that exist in this slab (wave-uniform)
+
+    // ---- operand recipes of this frequency ----
+    const int fi = xi >> 2, fj = xi & 3;
+    // dM = A dY A^T:  A rows  0: +y0   1: +y0 +y1   2: +y0 -y1   3: -y1   (same for the columns: even / odd pixel).
+    // Only the non-zero terms are read: 1, 2 or 4 of them (2.25 on average over the 16 frequencies).
+    const int nr = (fi == 1 || fi == 2) ? 2 : 1, nc = (fj == 1 || fj == 2) ? 2 : 1;
+    const int arow = fi == 3 ? 1 : 0, acol = fj == 3 ? 1 : 0;              // first (or only) row / half read
+    const float sr0 = fi == 3 ? -1.f : 1.f, sr1 = fi == 2 ? -1.f : 1.f;      // sign of the first / second row term
+    const float sc0 = fj == 3 ? -1.f : 1.f, sc1 = fj == 2 ? -1.f : 1.f;
+    const int aterms = nr * nc;                                              // 1, 2 or 4 (wave-uniform)
+    // V = B^T d B:  rows  0: +d0 -d2   1: +d1 +d2   2: -d1 +d2   3: +d1 -d3   (patch index p = 2*idx + half)
+    const int pa0 = fi == 0 ? 0 : 1, pa1 = fi == 3 ? 3 : 2;
+    const int pb0 = fj == 0 ? 0 : 1, pb1 = fj == 3 ? 3 : 2;
+    const float sa0 = fi == 2 ? -1.f : 1.f, sa1 = (fi == 0 || fi == 3) ? -1.f : 1.f;
+    const float sb0 = fj == 2 ? -1.f : 1.f, sb1 = (fj == 0 || fj == 3) ? -1.f : 1.f;
+    const float b00 = sa0 * sb0, b01 = sa0 * sb1, b10 = sa1 * sb0, b11 = sa1 * sb1;
+    // LDS offsets (floats) of the four terms; tile column c = 4*kstep + kq is added through the lane / immediates
+    const int abase = l16 * WW_PSO + kq + arow * 32 + acol * 16;            // [row][half][idx]
+    // term 0: (arow, acol); term 1: the second half if nc == 2, else the second row; terms 2, 3: second row
+    const int oa0 = abase, oa1 = abase + (nc == 2 ? 16 : 32), oa2 = abase + 32, oa3 = abase + 48;
+    const float as0 = sr0 * sc0, as1 = (nc == 2) ? sr0 * sc1 : sr1 * sc0, as2 = sr1 * sc0, as3 = sr1 * sc1;
+    const int bbase = WW_CO * WW_PSO + l16 * WW_PSI + kq;
+    auto xoff = [&](int pr, int pc) { return pr * WW_XR + (pc & 1) * 17 + (pc >> 1); };
+    const int ob00 = bbase + xoff(pa0, pb0), ob01 = bbase + xoff(pa0, pb1);
+    const int ob10 = bbase + xoff(pa1, pb0), ob11 = bbase + xoff(pa1, pb1);
+
+    // ---- LDS-DMA of one pixel tile (buffer bounds check zero-fills everything outside the image / channel range) ----
+    constexpr unsigned OOB = 0x40000000u;
+    struct TileAddr {
+        __amdgpu_buffer_rsrc_t rd, ri;
+        unsigned loff_d, loff_i;
+        int gyW;        // (gy * W) of this wave's input row, or -1 if the row is outside the image
+    };
+    const int irow = xi & 3;            // input-tile row this wave loads (of 4), channels (xi >> 2) + 4 * k
+    auto tile_addr = [&](int tile) {
+        TileAddr ta;
+        const int b = tile / tpi;
+        const int tr = tile - b * tpi;
+        const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
+        const int y0 = ty * WW_TH, x0 = tx * WW_TW;
+        {   // dY: lane -> (row, half, idx): pixel column 2*idx + half
+            const int r = lane >> 5, qq = lane & 31;
+            const int col = (qq < 16) ? 2 * qq : 2 * (qq - 16) + 1;
+            ta.loff_d = ((y0 + r < H) && (x0 + col < W)) ? (unsigned)((y0 + r) * W + x0 + col) * 4u : OOB;
+        }
+        {   // input with halo: lane < 17 -> even halo column 2*lane, lane 17..33 -> odd halo column 2*(lane-17)+1
+            const int hc = (lane < 17) ? 2 * lane : 2 * (lane - 17) + 1;
+            const int gx = x0 - 1 + hc;
+            ta.loff_i = (lane < WW_XR && gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
+        }
+        ta.rd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dout + ((size_t)b * p.Cout + (size_t)cb * WW_CO) * HW), 0, WW_CO * HW * 4, 0x00020000);
+        ta.ri = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in + ((size_t)b * p.Cin + ci0) * HW), 0, nci * HW * 4, 0x00020000);
+        const int gy = y0 + irow - 1;
+        ta.gyW = (gy >= 0 && gy < H) ? gy * W : -1;
+        return ta;
+    };
+    // 5 dY planes + 12 input rows per wave, cut into 6 groups: group g < 5 carries dY plane xi + 16 g; every group
+    // carries input rows of channels (xi >> 2) + 4 * (2g) and + 4 * (2g + 1)
+    auto issue_group = [&](const TileAddr& ta, float* buf, int g) {
+        if (g < 5) {
+            const int col = xi + 16 * g;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ta.rd, (lds_ptr)(buf + col * WW_PSO), 4,
+                                                     (int)(ta.loff_d + (unsigned)(col * HW) * 4u), 0, 0, 0);
+        }
+        if (lane < WW_XR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int cil = (xi >> 2) + 4 * (2 * g + i);
+                const unsigned roff = (cil < nci && ta.gyW >= 0) ? (unsigned)(cil * HW + ta.gyW) * 4u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    ta.ri, (lds_ptr)(buf + WW_CO * WW_PSO + cil * WW_PSI + irow * WW_XR), 4, (int)(ta.loff_i + roff), 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool dobias = p.gb != nullptr && cib == 0 && xi == 5;      // frequency (1,1): dM = sum of the 2x2 block
+
+    int it = 0;
+    if (s < p.ntiles) {
+        const TileAddr ta = tile_addr(s);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) issue_group(ta, smem, g);
+    }
+    for (int tile = s; tile < p.ntiles; tile += p.S, ++it) {
+        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+        const float* cur = smem + (it & 1) * WW_BUF;
+        float* nxt = smem + ((it + 1) & 1) * WW_BUF;
+        const bool pf = tile + p.S < p.ntiles;
+        TileAddr ta{};
+        if (pf) ta = tile_addr(tile + p.S);
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
+            if (pf) {
+                issue_group(ta, nxt, j);
+                if (j < 2) issue_group(ta, nxt, j + 4);
+            }
+            float a[5], bv[3];
+            const float* qd = cur + 4 * j;
+            if (aterms == 4) {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    const float* q = qd + mt * 16 * WW_PSO;
+                    a[mt] = as0 * q[oa0] + as1 * q[oa1] + as2 * q[oa2] + as3 * q[oa3];
+                }
+            } else if (aterms == 2) {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) {
+                    const float* q = qd + mt * 16 * WW_PSO;
+                    a[mt] = as0 * q[oa0] + as1 * q[oa1];
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * qd[mt * 16 * WW_PSO + oa0];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                const float* qx = cur + nt * 16 * WW_PSI + 4 * j;
+                bv[nt] = b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
+            }
+            if (dobias) {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) bsum[mt] += a[mt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                if (nt < nnt) {
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: dg = G^T dU G per (co, ci), one 16-channel M tile at a time through LDS ----
+    // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];   t[i][b] = sum_j dU[i][j] G[j][b];   dg[a][b] = sum_i G[i][a] t[i][b]
+    float* sE = smem;              // [xi][16 co][WW_ESTRIDE]  (12.5 K floats, inside the stage buffers)
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) {          // (fully unrolled: a dynamic index would push acc[] into scratch)
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                // C layout: col = lane&15 -> ci (N), row = (lane>>4)*4 + r -> co (M)
+                sE[(xi * 16 + kq * 4 + r) * WW_ESTRIDE + nt * 16 + l16] = acc[mt][nt][r];
+        __syncthreads();
+        // thread (co = wave, ci = lane)
+        const int ci = ci0 + lane;
+        const int co = cb * WW_CO + mt * 16 + xi;
+        if (lane < WW_CI && ci < p.Cin) {
+            float u[16];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) u[f] = sE[(f * 16 + xi) * WW_ESTRIDE + lane];
+            float t[4][3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float h1 = 0.5f * (u[i * 4 + 1] + u[i * 4 + 2]), h2 = 0.5f * (u[i * 4 + 1] - u[i * 4 + 2]);
+                t[i][0] = u[i * 4 + 0] + h1;
+                t[i][1] = h2;
+                t[i][2] = h1 + u[i * 4 + 3];
+            }
+            float* g = p.gw + ((size_t)co * 9) * p.Cin + ci;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const float h1 = 0.5f * (t[1][b] + t[2][b]), h2 = 0.5f * (t[1][b] - t[2][b]);
+                atomicAdd(g + (size_t)(0 * 3 + b) * p.Cin, t[0][b] + h1);
+                atomicAdd(g + (size_t)(1 * 3 + b) * p.Cin, h2);
+                atomicAdd(g + (size_t)(2 * 3 + b) * p.Cin, h1 + t[3][b]);
+            }
+        }
+    }
+    if (dobias) {
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            float v = bsum[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) atomicAdd(&p.gb[cb * WW_CO + mt * 16 + l16], v);
+        }
+    }
+}
+
+}  // namespace sinddm
