@@ -21,6 +21,11 @@
 
 namespace sinddm {
 
+// compile-time timing ablations (-DSINDDM_WW_ABL=bits; results are wrong): 1 no DMA after the first tile, 2 no operand reads
+#ifndef SINDDM_WW_ABL
+#define SINDDM_WW_ABL 0
+#endif
+
 constexpr int WW_THREADS = 1024;
 constexpr int WW_CO = 80, WW_CI = 48;
 constexpr int WW_TW = 32, WW_TH = 2;                 // pixel tile = one row of 16 2x2 tiles
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
         __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
         const float* cur = smem + (it & 1) * WW_BUF;
         float* nxt = smem + ((it + 1) & 1) * WW_BUF;
-        const bool pf = tile + p.S < p.ntiles;
+        const bool pf = tile + p.S < p.ntiles && !(SINDDM_WW_ABL & 1);
         TileAddr ta{};
         if (pf) ta = tile_addr(tile + p.S);
 #pragma unroll 1
@@ -166,7 +171,10 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
             }
             float a[5], bv[3];
             const float* qd = cur + 4 * j;
-            if (aterms == 4) {
+            if (SINDDM_WW_ABL & 2) {
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * (float)(j + mt);
+            } else if (aterms == 4) {
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) {
                     const float* q = qd + mt * 16 * WW_PSO;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 const float* qx = cur + nt * 16 * WW_PSI + 4 * j;
-                bv[nt] = b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
+                bv[nt] = (SINDDM_WW_ABL & 2) ? b00 * (float)(j - nt) : b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
             }
             if (dobias) {
 #pragma unroll
