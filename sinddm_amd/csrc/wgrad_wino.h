@@ -6,8 +6,9 @@
 // 16 frequency GEMMs with K = number of 2x2 tiles = pixels/4 instead of 9 GEMMs with K = pixels: 2.25x fewer MFMAs
 // than the direct weight gradient (autograd of the convs of reference SinDDM/models.py:63,65 via functions.py:97-102).
 //
-// Mapping: a 16-wave workgroup per CU owns an (80 co x 48 ci) slab and a strided subset of the 2x32-pixel tiles
-// (16 tiles = 4 k-steps of v_mfma_f32_16x16x4_f32 each); WAVE xi owns frequency xi: 5x3 accumulator tiles.
+// Mapping: a 16-wave workgroup per CU owns an (80 co x 48 ci) slab and a strided subset of the 4x16-pixel tiles
+// (2 x 8 2x2-tiles = 4 k-steps of v_mfma_f32_16x16x4_f32 each; a dY plane is ONE and an input halo plane TWO
+// whole-wave DMA instructions); WAVE xi owns frequency xi: 5x3 accumulator tiles.
 // Both operands are built on the fly from LDS: dM_xi from the dY tile (<= 4 signed reads), V_xi from the input
 // halo tile (4 signed reads), like the forward kernel's V.  The tiles are LDS-DMA'd with the pixel columns
 // DE-INTERLEAVED (a row is stored [even columns | odd columns]; the gather happens in the per-lane global offsets),
@@ -28,11 +29,12 @@ namespace sinddm {
 
 constexpr int WW_THREADS = 1024;
 constexpr int WW_CO = 80, WW_CI = 48;
-constexpr int WW_TW = 32, WW_TH = 2;                 // pixel tile = one row of 16 2x2 tiles
-constexpr int WW_PSO = 2 * 32 + 2;                   // dY plane: [2 rows][even 16 | odd 16] + pad      (== 2 mod 32)
-constexpr int WW_XR = 34;                            // input row incl. halo: [even 17 | odd 17]
-constexpr int WW_PSI = 162;                          // input plane: 4 rows x 34 = 136 -> 162            (== 2 mod 32)
-constexpr int WW_BUF = WW_CO * WW_PSO + WW_CI * WW_PSI;   // floats per stage (13056 = 51 KB)
+constexpr int WW_TW = 16, WW_TH = 4;                 // pixel tile = 2 x 8 2x2-tiles (4 k-steps of 4 tile columns)
+constexpr int WW_PSO = 4 * 16 + 2;                   // dY plane: [4 rows][even 8 | odd 8] + pad        (== 2 mod 32)
+constexpr int WW_XR = 18;                            // input row incl. halo: [even 9 | odd 9]
+constexpr int WW_XP = 6 * WW_XR;                     // input plane: 6 rows x 18 = 108 floats = 2 wave instructions
+constexpr int WW_PSI = 130;                          // plane stride                                     (== 2 mod 32)
+constexpr int WW_BUF = WW_CO * WW_PSO + WW_CI * WW_PSI;   // floats per stage (11520 = 45 KB)
 constexpr int WW_ESTRIDE = WW_CI + 1;                // epilogue exchange [xi][16 co][48 ci + 1]
 
 struct WwArgs {
@@ -82,23 +84,25 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
     const float sb0 = fj == 2 ? -1.f : 1.f, sb1 = (fj == 0 || fj == 3) ? -1.f : 1.f;
     const float b00 = sa0 * sb0, b01 = sa0 * sb1, b10 = sa1 * sb0, b11 = sa1 * sb1;
     // LDS offsets (floats) of the four terms; tile column c = 4*kstep + kq is added through the lane / immediates
-    const int abase = l16 * WW_PSO + kq + arow * 32 + acol * 16;            // [row][half][idx]
+    const int abase = l16 * WW_PSO + kq + arow * 16 + acol * 8;             // plane = [row][half][idx]
     // term 0: (arow, acol); term 1: the second half if nc == 2, else the second row; terms 2, 3: second row
-    const int oa0 = abase, oa1 = abase + (nc == 2 ? 16 : 32), oa2 = abase + 32, oa3 = abase + 48;
+    const int oa0 = abase, oa1 = abase + (nc == 2 ? 8 : 16), oa2 = abase + 16, oa3 = abase + 24;
     const float as0 = sr0 * sc0, as1 = (nc == 2) ? sr0 * sc1 : sr1 * sc0, as2 = sr1 * sc0, as3 = sr1 * sc1;
     const int bbase = WW_CO * WW_PSO + l16 * WW_PSI + kq;
-    auto xoff = [&](int pr, int pc) { return pr * WW_XR + (pc & 1) * 17 + (pc >> 1); };
+    auto xoff = [&](int pr, int pc) { return pr * WW_XR + (pc & 1) * 9 + (pc >> 1); };
     const int ob00 = bbase + xoff(pa0, pb0), ob01 = bbase + xoff(pa0, pb1);
     const int ob10 = bbase + xoff(pa1, pb0), ob11 = bbase + xoff(pa1, pb1);
 
     // ---- LDS-DMA of one pixel tile (buffer bounds check zero-fills everything outside the image / channel range) ----
+    // dY: 80 planes of 64 floats, one whole-wave instruction each (5 per wave).  Input: 48 halo planes of 108 floats,
+    // two instructions each; wave w always moves half q = w & 1 of channels (w >> 1) + 8 k (6 per wave), so one
+    // per-lane offset register per operand describes the gather (recomputed per tile for the image borders).
     constexpr unsigned OOB = 0x40000000u;
     struct TileAddr {
         __amdgpu_buffer_rsrc_t rd, ri;
         unsigned loff_d, loff_i;
-        int gyW;        // (gy * W) of this wave's input row, or -1 if the row is outside the image
     };
-    const int irow = xi & 3;            // input-tile row this wave loads (of 4), channels (xi >> 2) + 4 * k
+    const int xq = xi & 1;
     auto tile_addr = [&](int tile) {
         TileAddr ta;
         const int b = tile / tpi;
@@ -106,40 +110,36 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
         const int ty = tr / p.tilesX, tx = tr - ty * p.tilesX;
         const int y0 = ty * WW_TH, x0 = tx * WW_TW;
         {   // dY: lane -> (row, half, idx): pixel column 2*idx + half
-            const int r = lane >> 5, qq = lane & 31;
-            const int col = (qq < 16) ? 2 * qq : 2 * (qq - 16) + 1;
+            const int r = lane >> 4, rem = lane & 15;
+            const int col = 2 * (rem & 7) + (rem >> 3);
             ta.loff_d = ((y0 + r < H) && (x0 + col < W)) ? (unsigned)((y0 + r) * W + x0 + col) * 4u : OOB;
         }
-        {   // input with halo: lane < 17 -> even halo column 2*lane, lane 17..33 -> odd halo column 2*(lane-17)+1
-            const int hc = (lane < 17) ? 2 * lane : 2 * (lane - 17) + 1;
-            const int gx = x0 - 1 + hc;
-            ta.loff_i = (lane < WW_XR && gx >= 0 && gx < W) ? (unsigned)gx * 4u : OOB;
+        {   // input halo plane element e = 64 q + lane -> (row, half, idx): halo column 2*idx + half
+            const int e = xq * 64 + lane;
+            const int r = (e * 3641) >> 16;                    // e / 18 for e < 128
+            const int rem = e - r * WW_XR;
+            const int hc = (rem < 9) ? 2 * rem : 2 * (rem - 9) + 1;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + hc;
+            ta.loff_i = (e < WW_XP && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (unsigned)(gy * W + gx) * 4u : OOB;
         }
         ta.rd = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.dout + ((size_t)b * p.Cout + (size_t)cb * WW_CO) * HW), 0, WW_CO * HW * 4, 0x00020000);
         ta.ri = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.in + ((size_t)b * p.Cin + ci0) * HW), 0, nci * HW * 4, 0x00020000);
-        const int gy = y0 + irow - 1;
-        ta.gyW = (gy >= 0 && gy < H) ? gy * W : -1;
         return ta;
     };
-    // 5 dY planes + 12 input rows per wave, cut into 6 groups: group g < 5 carries dY plane xi + 16 g; every group
-    // carries input rows of channels (xi >> 2) + 4 * (2g) and + 4 * (2g + 1)
+    // 11 instructions per wave in 6 groups: group g < 5 carries dY plane xi + 16 g; every group carries one input
+    // half-plane (channel (xi >> 1) + 8 g)
     auto issue_group = [&](const TileAddr& ta, float* buf, int g) {
         if (g < 5) {
             const int col = xi + 16 * g;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ta.rd, (lds_ptr)(buf + col * WW_PSO), 4,
                                                      (int)(ta.loff_d + (unsigned)(col * HW) * 4u), 0, 0, 0);
         }
-        if (lane < WW_XR) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int cil = (xi >> 2) + 4 * (2 * g + i);
-                const unsigned roff = (cil < nci && ta.gyW >= 0) ? (unsigned)(cil * HW + ta.gyW) * 4u : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    ta.ri, (lds_ptr)(buf + WW_CO * WW_PSO + cil * WW_PSI + irow * WW_XR), 4, (int)(ta.loff_i + roff), 0, 0, 0);
-            }
-        }
+        const int cil = (xi >> 1) + 8 * g;
+        const unsigned coff = (cil < nci) ? (unsigned)(cil * HW) * 4u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ta.ri, (lds_ptr)(buf + WW_CO * WW_PSO + cil * WW_PSI + xq * 64), 4,
+                                                 (int)(ta.loff_i + coff), 0, 0, 0);
     };
 
     f32x4 acc[5][3];
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
                 if (j < 2) issue_group(ta, nxt, j + 4);
             }
             float a[5], bv[3];
-            const float* qd = cur + 4 * j;
+            const float* qd = cur + (j >> 1) * 32 + (j & 1) * 4;       // tile row j>>1, tile columns 4*(j&1) + kq
             if (SINDDM_WW_ABL & 2) {
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * (float)(j + mt);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
             }
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
-                const float* qx = cur + nt * 16 * WW_PSI + 4 * j;
+                const float* qx = cur + nt * 16 * WW_PSI + (j >> 1) * 36 + (j & 1) * 4;
                 bv[nt] = (SINDDM_WW_ABL & 2) ? b00 * (float)(j - nt) : b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
             }
             if (dobias) {
