@@ -367,6 +367,122 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(WgradArgs p) {
     }
 }
 
+// -------------------------------------------------------------------------------------
+// 1x1 weight gradient (res_conv, reference SinDDM/models.py:67) for Cout % 80 == 0:  gw[co][ci] += sum_px dout[co][px] in[ci][px]
+// HBM-bound (4*(Cin + Cout) bytes per pixel for 2*Cin*Cout FLOP): what matters is reading dout / in once.  A 16-wave
+// workgroup owns an 80(co) x 80(ci) slab (the K-split kernel above re-read dout once per 16 input channels);
+// wave (k-group, ci-tile) of the 15 compute waves holds 5 co-tiles and takes every third k-step of a flat 64-pixel
+// tile, wave 15 only moves data and sums dout for the bias.  Pixels are flattened (no halo): a tile is 64 consecutive
+// pixels of one image, one whole-wave DMA instruction per channel.
+// -------------------------------------------------------------------------------------
+constexpr int W1_C = 80;
+constexpr int W1_PIX = 64;
+constexpr int W1_PS = W1_PIX + 2;                          // plane stride == 2 (mod 32)
+constexpr int W1_BUF = 2 * W1_C * W1_PS;                   // dout planes + input planes per stage (10560 floats)
+
+__global__ __launch_bounds__(1024) void wgrad1x1_kernel(WgradArgs p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int slot = id >> 3;
+    const int pairs = p.coblks * p.ciblks;
+    const int q = slot % pairs;
+    const int s = (slot / pairs) * 8 + xcd;
+    const int cb = q / p.ciblks, cib = q - cb * p.ciblks;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / 5, cit = wave - kg * 5;      // k-group (0..2; 3 = the data-moving wave), ci tile
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int HW = p.H * p.W;
+    const int tpi = p.tilesX;                            // flat 64-pixel tiles per image
+    const int ci0 = cib * W1_C;
+    const int nci = min(W1_C, p.Cin - ci0);
+    constexpr unsigned OOB = 0x40000000u;
+
+    // pixel split s owns a contiguous tile range; (image, tile-in-image) advance incrementally
+    const int per = (p.ntiles + p.S - 1) / p.S;
+    const int t_begin = s * per, t_end = min(p.ntiles, t_begin + per);
+    int nb = t_begin / tpi, nt_ = t_begin - nb * tpi;
+    // this wave stages dout planes wave + 16 g and input planes wave + 16 g (g < 5): 10 instructions per tile
+    auto issue = [&](float* buf) {
+        const int px = nt_ * W1_PIX + lane;
+        const unsigned loff = px < HW ? (unsigned)px * 4u : OOB;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dout + ((size_t)nb * p.Cout + (size_t)cb * W1_C) * HW), 0, W1_C * HW * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in + ((size_t)nb * p.Cin + ci0) * HW), 0, nci * HW * 4, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            const int ch = wave + 16 * g;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr)(buf + ch * W1_PS), 4, (int)(loff + (unsigned)(ch * HW) * 4u), 0, 0, 0);
+            const unsigned coff = ch < nci ? (unsigned)(ch * HW) * 4u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (lds_ptr)(buf + (W1_C + ch) * W1_PS), 4, (int)(loff + coff), 0, 0, 0);
+        }
+        if (++nt_ == tpi) { nt_ = 0; ++nb; }
+    };
+
+    f32x4 acc[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool active = wave < 15 && ci0 + cit * 16 < p.Cin;
+    const bool dobias = p.gb != nullptr && cib == 0 && wave == 15;
+    const int aBase = l16 * W1_PS + kq;
+    const int bBase = (W1_C + cit * 16 + l16) * W1_PS + kq;
+
+    int it = 0;
+    if (t_begin < t_end) issue(smem);
+    for (int tile = t_begin; tile < t_end; ++tile, ++it) {
+        __syncthreads();
+        const float* cur = smem + (it & 1) * W1_BUF;
+        if (tile + 1 < t_end) issue(smem + ((it + 1) & 1) * W1_BUF);
+        if (active) {
+            // k-steps j = kg, kg + 3, ... of the 16 (4 consecutive pixels each)
+#pragma unroll
+            for (int jj = 0; jj < 6; ++jj) {
+                const int j = kg + 3 * jj;
+                if (j < 16) {
+                    const float bv = cur[bBase + 4 * j];
+#pragma unroll
+                    for (int mt = 0; mt < 5; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[aBase + mt * 16 * W1_PS + 4 * j], bv, acc[mt], 0, 0, 0);
+                }
+            }
+        } else if (dobias) {
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) bsum[mt] += cur[aBase + mt * 16 * W1_PS + 4 * j];
+        }
+    }
+
+    if (active) {
+        const int ci = ci0 + cit * 16 + l16;
+        if (ci < p.Cin) {
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // C layout: col = lane&15 -> ci (N), row = (lane>>4)*4 + r -> co (M); 16 lanes hit one 64-byte line
+                    const int co = cb * W1_C + mt * 16 + kq * 4 + r;
+                    atomicAdd(p.gw + (size_t)co * p.Cin + ci, acc[mt][r]);
+                }
+        }
+    }
+    if (dobias) {
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+            float v = bsum[mt];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) atomicAdd(&p.gb[cb * W1_C + mt * 16 + l16], v);
+        }
+    }
+}
+
 // gw[co][ci][tap] += scr[co][tap][ci]   (unpacks the staging slab of wgrad3x3_kernel)
 __global__ void wgrad_unstage_kernel(const float* __restrict__ scr, float* __restrict__ gw, int Cin, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;    // index into gw
@@ -420,6 +536,25 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(pairs * S)), dim3(WW_THREADS), lds, st, w);
         SINDDM_LAUNCH_CHECK();
         hipLaunchKernelGGL(wgrad_unstage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scr, gw, Cin, n);
+        SINDDM_LAUNCH_CHECK();
+        return 0;
+    }
+    static const int w1 = getenv("SINDDM_WGRAD_W1") ? atoi(getenv("SINDDM_WGRAD_W1")) : 1;
+    if (taps == 1 && Cout % W1_C == 0 && w1) {
+        if ((size_t)W1_C * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
+        a.coblks = Cout / W1_C;
+        a.ciblks = (Cin + W1_C - 1) / W1_C;
+        a.tilesX = (H * W + W1_PIX - 1) / W1_PIX;      // flat tiles per image
+        a.tilesY = 1;
+        a.ntiles = B * a.tilesX;
+        const int pairs = a.coblks * a.ciblks;
+        int S = (device_cu_count() / pairs) / 8 * 8;
+        if (S < 8) S = 8;
+        const int cap = (a.ntiles + 7) / 8 * 8;
+        if (S > cap) S = cap;
+        a.S = S;
+        constexpr size_t lds = (size_t)2 * W1_BUF * sizeof(float);
+        hipLaunchKernelGGL(wgrad1x1_kernel, dim3((unsigned)(pairs * S)), dim3(1024), lds, st, a);
         SINDDM_LAUNCH_CHECK();
         return 0;
     }
