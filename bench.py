@@ -56,11 +56,29 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback of the hot path exists)")
+    # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): SINDDM_BENCH_BACKEND=gloo stages the tiny timing
+    # collectives through the host and SINDDM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0; production = nccl/RCCL
+    backend = os.environ.get("SINDDM_BENCH_BACKEND", "nccl")
+    if os.environ.get("SINDDM_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            td.init_process_group(backend="nccl", device_id=dev)
+        else:
+            td.init_process_group(backend=backend)
+
+    def allreduce_max(t):
+        if world > 1:
+            if backend == "nccl":
+                td.all_reduce(t, op=td.ReduceOp.MAX)
+            else:
+                h = t.cpu()
+                td.all_reduce(h, op=td.ReduceOp.MAX)
+                t.copy_(h)
+        return t
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
 
     from sinddm_amd import _lib
@@ -99,9 +117,7 @@ def main():
     conv_ms, conv_n, conv_fl, conv_ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
     _lib.check(lib.sinddm_prof_end2(C.byref(conv_ms), C.byref(conv_n), C.byref(conv_fl), C.byref(conv_ex)),
                "sinddm_prof_end2")
-    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
+    tt = allreduce_max(torch.tensor([dt], device=dev, dtype=torch.float64))
     dt = float(tt)
     assert torch.isfinite(img).all()
 
@@ -146,14 +162,15 @@ def main():
             cur = d.sample_via_scale(B, cur, s=si, scale_mul=mul, custom_sample=True, custom_img_size_idx=si,
                                      custom_t=d.num_timesteps_ideal[si])
         if world > 1:
-            out = torch.empty((world * B,) + tuple(cur.shape[1:]), device=dev)
-            td.all_gather_into_tensor(out, cur.contiguous())
-            cur = out
+            from sinddm_amd import dist as sdist
+            if backend == "nccl":
+                out = torch.empty((world * B,) + tuple(cur.shape[1:]), device=dev)
+                td.all_gather_into_tensor(out, cur.contiguous())
+                cur = out
+            else:
+                cur = sdist.gather_batch(cur.cpu(), world * B).to(dev)
         barrier()
-        ft = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        if world > 1:
-            td.all_reduce(ft, op=td.ReduceOp.MAX)
-        ft = float(ft)
+        ft = float(allreduce_max(torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)))
         evals = sum(d.num_timesteps_ideal)
         pix_steps = 0
         for si in range(n_scales):
