@@ -565,13 +565,25 @@ class MultiScaleGaussianDiffusion(nn.Module):
     def p_sample_loop(self, shape, s):                                     # models.py:462-487
         device = self.betas.device
         img = self._draw("init", shape, s, 0, device)
+        self._dump_interm(img, s, f'input_noise_s-{s}.png')
         if self.sample_limited_t and s < (self.n_scales - 1):
             t_min = self.num_timesteps_ideal[s + 1]
         else:
             t_min = 0
         for i in reversed(range(t_min, self.num_timesteps)):
             img = self._p_sample_host_t(img, i, s)
+            self._dump_interm(img, s, f'output_t-{i:03}_s-{s}.png')
         return img
+
+    def _dump_interm(self, img, s, name):
+        """save_interm=True (models.py:469-485,520-546): PNG grid of the running sample after every step (debug aid;
+        the per-step `denoised_t-*` dumps of x_recon are not produced -- x_recon only exists inside the fused kernel)."""
+        if not self.save_interm:
+            return
+        from .trainer import save_image
+        folder = Path(str(self.results_folder / f'interm_samples_scale_{s}'))
+        folder.mkdir(parents=True, exist_ok=True)
+        save_image((img + 1) * 0.5, str(folder / name), nrow=4)
 
     @torch.no_grad()
     def sample(self, batch_size=16, scale_0_size=None, s=0):               # models.py:489-499
@@ -588,6 +600,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
         self.img_prev_upsample = img                                        # x-tilde of this scale
         noise = self._draw("renoise", img.shape, s, 0, img.device)
         img = self._q_sample_impl(img, None, total_t, noise)                # models.py:518
+        self._dump_interm(img, s, f'noisy_input_s_{s}.png')
         if self.clip_mask is not None:
             raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
         if self.sample_limited_t and s < (self.n_scales - 1):
@@ -596,6 +609,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
             t_min = 0
         for i in reversed(range(t_min, total_t)):
             img = self._p_sample_host_t(img, i, s)
+            self._dump_interm(img, s, f'output_t-{i:03}_s-{s}.png')
         return img
 
     def target_size(self, s, scale_mul=(1, 1), custom_sample=False, custom_img_size_idx=0, custom_image_size=None):

@@ -259,3 +259,17 @@ def test_harmonization_mask_blend(golden, tmp_path):
     m = torch.from_numpy(dilate_mask(torch.from_numpy(mask.transpose(2, 0, 1).copy()).float().div(255), "harmonization")).float()
     assert torch.allclose(final, m * sample + (1 - m) * src, atol=2e-6)
     assert torch.isfinite(final).all()
+
+
+def test_save_interm_dumps(golden, tmp_path):
+    """save_interm=True writes the per-step PNG grids of the reference (models.py:469-485,520-546)."""
+    tr, meta = _trainer(golden, tmp_path, T=4)
+    d = tr.ema_model
+    d.save_interm = True
+    d.results_folder = tmp_path / "interm"
+    x0 = d.sample(batch_size=1)
+    d.sample_via_scale(1, x0, s=1, custom_t=2)
+    f0 = sorted(os.listdir(tmp_path / "interm" / "interm_samples_scale_0"))
+    f1 = sorted(os.listdir(tmp_path / "interm" / "interm_samples_scale_1"))
+    assert f0 == ["input_noise_s-0.png"] + [f"output_t-{i:03}_s-0.png" for i in range(4)]
+    assert f1 == ["noisy_input_s_1.png", "output_t-000_s-1.png", "output_t-001_s-1.png"]
