@@ -8,7 +8,8 @@ from sinddm_amd.models import SinDDMNet
 from sinddm_amd.synth import closed_form_state_dict, hash_randn
 
 dev = "cuda:0"
-B, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 411, 512
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+H, W = int(os.environ.get("BSC_H", 411)), int(os.environ.get("BSC_W", 512))
 net = SinDDMNet(dim=160, multiscale=True, device=dev).to(dev)
 net.load_state_dict(closed_form_state_dict(160))
 x = torch.randn(B, 3, H, W, device=dev)
