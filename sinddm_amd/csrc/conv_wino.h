@@ -64,7 +64,7 @@ template <int MT, int NTR, int ACT, int CPC>
 __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
     using WG = WinoGeom<NTR, CPC>;
     constexpr int NKS = 4 * CPC;                                   // k-steps (of 4 channels) per chunk
-    constexpr int WN_TH = WG::TH, WN_PLANE = WG::PLANE, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
+    constexpr int WN_TH = WG::TH, WN_PS = WG::PS, WN_IN_LIN = WG::IN_LIN;
     constexpr int WN_MSTRIDE = WG::MSTRIDE, MPP = WG::MPP;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     extern __shared__ __attribute__((aligned(16))) float smem[];

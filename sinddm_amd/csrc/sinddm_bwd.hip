@@ -185,7 +185,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
 }
 
 // -------------------------------------------------------------------------------------
-// 3x3 weight gradient for Cout % 80 == 0: one 15-wave workgroup per CU owns an 80(co) x 80(ci) x 9 slab.
+// Direct-form 3x3 weight gradient for Cout % 80 == 0 (used for C_in < 16 and as SINDDM_WGRAD_WINO=0 fallback; the
+// default is the Winograd-domain kernel of wgrad_wino.h): one 16-wave workgroup per CU owns an 80(co) x 80(ci) x 9 slab.
 // Wave (tap-row, ci-tile) accumulates 5 co-tiles x 3 taps (60 registers) over every pixel of the tile, so no
 // cross-wave reduction is needed and a 64-pixel tile (73 KB of LDS) feeds 3600 MFMAs: 2.4x fewer L2->LDS bytes
 // per FLOP than the K-split kernel above, whose DMA latency cost 38% of its time (ablation in DESIGN.md).
