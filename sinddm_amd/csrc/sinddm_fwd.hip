@@ -323,21 +323,39 @@ int dwconv_launch(const float* x, const float* w, const float* bias, const float
 __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int C, int HW) {
+    // 4 consecutive pixels per thread: 16-byte loads (4-byte aligned is enough for global memory), 8 channels in flight
     const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= HW) return;
     const float* src = a + (size_t)b * C * HW + p;
-    float o0 = bias[0], o1 = bias[1], o2 = bias[2];
-    for (int c = 0; c < C; ++c) {
-        const float v = src[(size_t)c * HW];
-        o0 = fmaf(w[c], v, o0);
-        o1 = fmaf(w[C + c], v, o1);
-        o2 = fmaf(w[2 * C + c], v, o2);
-    }
     float* dst = out + (size_t)b * 3 * HW + p;
-    dst[0] = o0;
-    dst[HW] = o1;
-    dst[2 * (size_t)HW] = o2;
+    if (p + 3 < HW) {
+        f32x4 o0{bias[0], bias[0], bias[0], bias[0]}, o1{bias[1], bias[1], bias[1], bias[1]},
+            o2{bias[2], bias[2], bias[2], bias[2]};
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)c * HW);
+            o0 += w[c] * v;
+            o1 += w[C + c] * v;
+            o2 += w[2 * C + c] * v;
+        }
+        *reinterpret_cast<f32x4*>(dst) = o0;
+        *reinterpret_cast<f32x4*>(dst + HW) = o1;
+        *reinterpret_cast<f32x4*>(dst + 2 * (size_t)HW) = o2;
+    } else {
+        for (int j = 0; p + j < HW; ++j) {
+            float o0 = bias[0], o1 = bias[1], o2 = bias[2];
+            for (int c = 0; c < C; ++c) {
+                const float v = src[(size_t)c * HW + j];
+                o0 = fmaf(w[c], v, o0);
+                o1 = fmaf(w[C + c], v, o1);
+                o2 = fmaf(w[2 * C + c], v, o2);
+            }
+            dst[j] = o0;
+            dst[HW + j] = o1;
+            dst[2 * (size_t)HW + j] = o2;
+        }
+    }
 }
 
 // =====================================================================================
@@ -528,7 +546,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         curb = sel[2];
     }
     const int HW = H * W;
-    hipLaunchKernelGGL(final_conv1x1_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, st, cur, params + P.fin_w,
+    hipLaunchKernelGGL(final_conv1x1_kernel, dim3(((HW + 3) / 4 + 255) / 256, B), dim3(256), 0, st, cur, params + P.fin_w,
                        params + P.fin_b, out, P.half, HW);
     SINDDM_LAUNCH_CHECK();
     return 0;
