@@ -50,7 +50,9 @@ struct WinoGeom {
     static constexpr int IN_LIN = CPC * WN_KC * PS;              // floats per raw-tile buffer (CPC x 16 channels)
     static constexpr int RAW_FLOATS = (2 * IN_LIN + 3) / 4 * 4;  // two buffers
     static constexpr int NTILES = NTR * 16;
-    static constexpr int MSTRIDE = NTILES + 1;                   // [xi][co][tiles + 1]
+    // [xi][co][tiles + pad]: 4 * MSTRIDE == 16 (mod 32) puts the two k-lane groups of a half-wave (rows kq*4 + r,
+    // 4 rows apart) on disjoint banks when the accumulators are written (stride NTILES + 1 = 49 was a 2-way conflict)
+    static constexpr int MSTRIDE = (NTILES + 4) / 8 * 8 + 4;
     // M tiles (16 channels each) exchanged per epilogue pass: two if the LDS budget (160 KB) allows
     static constexpr int MPP = ((RAW_FLOATS + 16 * 32 * MSTRIDE) * 4 <= 160 * 1024) ? 2 : 1;
     static constexpr int LDS_FLOATS = RAW_FLOATS + 16 * (16 * MPP) * MSTRIDE;
