@@ -218,6 +218,9 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ks & 1][mt], bv, acc[mt][nt], 0, 0, 0);
                     }
+#ifdef SINDDM_WINO_TIMING
+                    if (ks == 0 && nt == 0 && dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
                 }
                 if (ks < NKS - 2) load_w(ks & 1, it.cb, c, ks + 2);
                 if (ks == 1 && more && !(SINDDM_WINO_ABL & 4)) issue(it, c + 1, smem + ((c + 1) & 1) * WN_IN_LIN);

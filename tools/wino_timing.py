@@ -33,7 +33,9 @@ try:
             if t0.max() == 0:
                 continue
             base = t0.min()
-            print(f" chunk {c:2d}: start spread {t0.max()-t0.min():5d}  compute min/mean/max {int((t1-t0).min()):6d} {int((t1-t0).mean()):6d} {int((t1-t0).max()):6d}"
+            t3 = a[it, c, :, 3]
+            print(f" chunk {c:2d}: first MFMA group issued after min/mean/max {int((t3-t0).min()):5d} {int((t3-t0).mean()):5d} {int((t3-t0).max()):5d} |", end="")
+            print(f" start spread {t0.max()-t0.min():5d}  compute min/mean/max {int((t1-t0).min()):6d} {int((t1-t0).mean()):6d} {int((t1-t0).max()):6d}"
                   f"  barrier wait min/mean/max {int((t2-t1).min()):6d} {int((t2-t1).mean()):6d} {int((t2-t1).max()):6d}  chunk total {int(t2.max()-base):6d}")
         if a[it, :, :, 0].max() > 0:
             cc = [c for c in range(16) if a[it, c, :, 0].max() > 0]
