@@ -32,7 +32,6 @@ sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 rate)
 NET_FLOP_PER_PIXEL = 2_150_230     # one SinDDMNet forward, per pixel per sample
-CONV_FLOP_PER_PIXEL = 2 * (1_038_960 + 240 + 12_800 + 12_800)   # the 8 MFMA conv launches (3x3 + fused 1x1 residuals)
 
 
 def parse():
@@ -114,9 +113,14 @@ def main():
         img = d._p_sample_host_t(img, t_seq[i], s)
     barrier()
     dt = time.perf_counter() - t0
-    conv_ms, conv_n, conv_fl, conv_ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-    _lib.check(lib.sinddm_prof_end2(C.byref(conv_ms), C.byref(conv_n), C.byref(conv_fl), C.byref(conv_ex)),
-               "sinddm_prof_end2")
+    def prof(kind, reset):
+        ms, n, fl, ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(lib.sinddm_prof_end3(kind, C.byref(ms), C.byref(n), C.byref(fl), C.byref(ex), reset), "sinddm_prof_end3")
+        return ms.value, n.value, fl.value, ex.value
+
+    wino = os.environ.get("SINDDM_CONV_WINO", "1") != "0"
+    dom_ms, dom_n, dom_fl, dom_ex = prof(1 if wino else 3, 0)        # the dominant kernel family only
+    all_ms, all_n, all_fl, all_ex = prof(0, 1)                      # every MFMA convolution of the step
     tt = allreduce_max(torch.tensor([dt], device=dev, dtype=torch.float64))
     dt = float(tt)
     assert torch.isfinite(img).all()
@@ -124,32 +128,34 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
-    # ---- roofline of the dominant kernels: the MFMA convolutions of the step ----
-    # algorithmic FLOPs = SURVEY 8(d)'s per-pixel figure x pixels per step (direct-convolution count,
-    # also when the Winograd kernel executes only 16/36 of them)
+    # ---- roofline of the dominant kernel ----
+    # achieved = ALGORITHMIC FLOPs per launch (direct-convolution count 2*9*Cin*Cout per pixel of the layers this
+    # kernel runs; the Winograd kernel executes 16/36 of them) / its average launch duration, measured with HIP events
+    # around every launch on the launch stream inside the timed region.  The same kernel's average duration in
+    # profiles/*_bench_kernel_stats.txt (rocprofv3 --kernel-trace --stats) must agree with avg_launch_ms.
     px = B * H * W
-    launches_per_step = conv_n.value / max(1, args.steps)
-    alg_flops_per_launch = CONV_FLOP_PER_PIXEL * px / max(1.0, launches_per_step)
-    avg_launch_ms = conv_ms.value / max(1, conv_n.value)
-    achieved = alg_flops_per_launch / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
-    executed = conv_ex.value / (conv_ms.value * 1e-3) / 1e12 if conv_ms.value > 0 else 0.0
+    avg_launch_ms = dom_ms / max(1, dom_n)
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    executed = dom_ex / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("conv_bytes_per_launch")   # PMC passes, profiles/r01f_pmc_summary.txt
+            traffic = json.load(open(tpath)).get("conv_bytes_per_launch")   # PMC passes, profiles/r01k_pmc_summary.txt
         except Exception:
             traffic = None
-    wino = os.environ.get("SINDDM_CONV_WINO", "1") != "0"
     roofline = {"bound": "mfma",
-                "kernel": ("conv_wino_kernel<5> (Winograd F(2x2,3x3) on fp32 v_mfma_f32_16x16x4_f32) + conv_mfma_dma_kernel "
-                           "(1x1 projections, C_in=3 conv)" if wino else
+                "kernel": ("conv_wino_kernel<5,3,*> (Winograd F(2x2,3x3) 3x3 conv on fp32 v_mfma_f32_16x16x4_f32; 7 launches "
+                           "per step)" if wino else
                            "conv_mfma_dma_kernel<5,2,0,8> (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM 3x3 conv)"),
                 "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_flops_per_launch": round(dom_fl / max(1, dom_n)),
                 "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-                "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(conv_n.value),
-                "conv_share_of_step": round(conv_ms.value / (dt * 1e3), 4),
+                "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(dom_n),
+                "share_of_step": round(dom_ms / (dt * 1e3), 4),
+                "all_mfma_convs": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+                                   "launches": int(all_n), "share_of_step": round(all_ms / (dt * 1e3), 4)},
                 "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * args.steps / dt / 1e12, 2)}
 
     # ---- second half of the metric: one FULL multi-scale sample (all scales + all-gather) ----

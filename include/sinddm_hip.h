@@ -153,6 +153,10 @@ int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_
  * of their algorithmic FLOPs) */
 int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
                      double* conv_exec_flops_total);
+/* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino_kernel), 2 = 1x1 convs,
+ * 3 = direct 3x3 (conv_mfma_dma_kernel).  reset = 0 keeps the records so that several kinds can be queried. */
+int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total,
+                     double* exec_flops_total, int reset);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsinddm_hip.so")
 ABI_SYMBOLS = (
     "sinddm_abi_version", "sinddm_param_count", "sinddm_param_tensors", "sinddm_param_offset",
     "sinddm_packed_count", "sinddm_workspace_bytes", "sinddm_pack_weights", "sinddm_net_forward",
-    "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2",
+    "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2", "sinddm_prof_end3",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
 )
@@ -69,6 +69,8 @@ def load() -> C.CDLL:
         "sinddm_prof_end": (i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
         "sinddm_prof_end2": (i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double)]),
+        "sinddm_prof_end3": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_double), i]),
         "sinddm_train_workspace_bytes": (sz, [i, i, i, i]),
         "sinddm_packed_bwd_count": (i64, [i]),
         "sinddm_pack_weights_bwd": (i, [p, p, i, p]),

@@ -157,9 +157,7 @@ inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * (double)a.Cin2;
-        prof.flops += fl;
-        prof.exec_flops += fl;
-        ++prof.used;
+        prof.note(2, fl, fl);
     }
     SINDDM_LAUNCH_CHECK();
     return 0;

@@ -286,6 +286,13 @@ struct ConvProfiler {
     static constexpr int MAXREC = 8192;
     hipEvent_t ev[2 * MAXREC];
     int created = 0;
+    // per record: which kernel family (1 = Winograd 3x3, 2 = 1x1, 3 = direct 3x3) and its FLOP counts
+    unsigned char kind[MAXREC];
+    double rec_flops[MAXREC], rec_exec[MAXREC];
+    void note(int k, double fl, double ex) {
+        kind[used] = (unsigned char)k; rec_flops[used] = fl; rec_exec[used] = ex;
+        flops += fl; exec_flops += ex; ++used;
+    }
 };
 ConvProfiler& conv_profiler();
 
@@ -346,9 +353,7 @@ inline int conv_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * (9.0 * a.Cin * (a.nch3 > 0) + (double)a.Cin2 * (a.nch1 > 0));
-        prof.flops += fl;
-        prof.exec_flops += fl;
-        ++prof.used;
+        prof.note(3, fl, fl);
     }
     SINDDM_LAUNCH_CHECK();
     return 0;

@@ -658,22 +658,29 @@ int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_
 
 int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
                      double* conv_exec_flops_total) {
+    return sinddm_prof_end3(0, conv_ms_total, conv_launches, conv_flops_total, conv_exec_flops_total, 1);
+}
+
+int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total, double* exec_flops_total,
+                     int reset) {
     ConvProfiler& p = conv_profiler();
     p.on = false;
-    double ms = 0.0;
+    double ms = 0.0, fl = 0.0, ex = 0.0;
+    int64_t n = 0;
     for (int i = 0; i < p.used; ++i) {
+        if (kind != 0 && p.kind[i] != kind) continue;
         hipError_t e = hipEventSynchronize(p.ev[2 * i + 1]);
         if (e != hipSuccess) return (int)e;
         float t = 0.f;
         e = hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]);
         if (e != hipSuccess) return (int)e;
-        ms += t;
+        ms += t; fl += p.rec_flops[i]; ex += p.rec_exec[i]; ++n;
     }
-    if (conv_ms_total) *conv_ms_total = ms;
-    if (conv_launches) *conv_launches = p.used;
-    if (conv_flops_total) *conv_flops_total = p.flops;
-    if (conv_exec_flops_total) *conv_exec_flops_total = p.exec_flops;
-    p.used = 0;
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = n;
+    if (flops_total) *flops_total = fl;
+    if (exec_flops_total) *exec_flops_total = ex;
+    if (reset) { p.used = 0; p.flops = 0.0; p.exec_flops = 0.0; }
     return 0;
 }
 
