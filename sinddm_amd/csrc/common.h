@@ -40,10 +40,18 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 
 __device__ __forceinline__ float gelu_erf_grad(float v) {
-    // d/dv [0.5 v (1+erf(v/sqrt2))] = 0.5(1+erf(v/sqrt2)) + v * exp(-v^2/2)/sqrt(2 pi)
-    const float cdf = 0.5f * (1.0f + erf_fast(v * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
-    return cdf + v * pdf;
+    // d/dv [0.5 v (1+erf(v/sqrt2))] = 0.5(1+erf(v/sqrt2)) + v * exp(-v^2/2)/sqrt(2 pi).
+    // erf_fast's exp(-x^2) at x = v/sqrt2 IS the exp(-v^2/2) of the density: evaluated once for both terms.
+    const float ax = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __expf(-0.5f * v * v);
+    const float erfv = copysignf(fmaf(-poly, e, 1.0f), v);
+    return fmaf(v, 0.39894228040143267794f * e, 0.5f * (1.0f + erfv));
 }
 
 // ---- geometry of the implicit-GEMM 3x3 conv tile (shared by forward / dgrad) ----
