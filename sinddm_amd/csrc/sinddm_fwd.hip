@@ -227,13 +227,14 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
 
 // =====================================================================================
 // depthwise 5x5 + bias + per-sample condition      reference SinDDM/models.py:61,70,77
-// HBM-bound: 8 B per (channel,pixel).  A 16x64 tile is staged with its 2-pixel halo in LDS; wave w owns
-// tile rows 4w..4w+3 and lane l owns column l, so every global store (and every LDS read) of a wave is
-// 64 consecutive floats.  With flip=1 the taps are mirrored (transposed conv = data gradient) and
-// `addt` is added to the result (residual-path gradient).
+// HBM-bound: 8 B per (channel,pixel).  A 16x128 tile is staged with its 2-pixel halo in LDS; wave w owns tile rows
+// 4w..4w+3 and lane l owns columns l and l+64: one ds_read2_b32 fetches both (every wave access is 2 x 64
+// consecutive floats) and the 25 taps become packed FMAs (v_pk_fma_f32: weight broadcast x column pair) -- the
+// kernel is as much VALU- as bandwidth-limited (25 FMA per 8 bytes).  With flip=1 the taps are mirrored (transposed
+// conv = data gradient) and `addt` is added to the result (residual-path gradient).
 // =====================================================================================
-constexpr int DW_TH = 16, DW_TW = 64, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
-constexpr int DW_NX = 4;   // x-tiles per workgroup: all their loads are in flight together (latency-bound otherwise)
+constexpr int DW_TH = 16, DW_TW = 128, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
+constexpr int DW_NX = 2;   // x-tiles per workgroup: all their loads are in flight together (latency-bound otherwise)
 
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
@@ -278,29 +279,35 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     for (int t = 0; t < DW_NX; ++t) {
         const int x0 = xg0 + t * DW_TW;
         if (x0 >= W) break;
-        float o[4] = {add, add, add, add};
+        f32x2 o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f32x2{add, add};
 #pragma unroll
         for (int dy = 0; dy < 8; ++dy) {
-            float v[5];
+            f32x2 v[5];
+            const float* row = &tile[t][(wv * 4 + dy) * DW_RS + lane];
 #pragma unroll
-            for (int dx = 0; dx < 5; ++dx) v[dx] = tile[t][(wv * 4 + dy) * DW_RS + lane + dx];
+            for (int dx = 0; dx < 5; ++dx) v[dx] = f32x2{row[dx], row[dx + 64]};      // columns lane+dx and lane+64+dx
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ky = dy - r;
                 if (ky >= 0 && ky < 5) {
 #pragma unroll
-                    for (int dx = 0; dx < 5; ++dx) o[r] = fmaf(wk[ky * 5 + dx], v[dx], o[r]);
+                    for (int dx = 0; dx < 5; ++dx) o[r] += wk[ky * 5 + dx] * v[dx];
                 }
             }
         }
-        const int gx = x0 + lane;
-        if (gx < W) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gy = y0 + wv * 4 + r;
-                if (gy < H) {
-                    const size_t oidx = plane + (size_t)gy * W + gx;
-                    out[oidx] = addt ? o[r] + addt[oidx] : o[r];
+        for (int h = 0; h < 2; ++h) {
+            const int gx = x0 + lane + 64 * h;
+            if (gx < W) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gy = y0 + wv * 4 + r;
+                    if (gy < H) {
+                        const size_t oidx = plane + (size_t)gy * W + gx;
+                        out[oidx] = addt ? o[r][h] + addt[oidx] : o[r][h];
+                    }
                 }
             }
         }
