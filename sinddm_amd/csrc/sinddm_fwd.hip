@@ -325,6 +325,50 @@ int dwconv_launch(const float* x, const float* w, const float* bias, const float
 }
 
 // =====================================================================================
+// first 3x3 conv of the network (C_in = 3 -> C_out, + bias + GELU)      reference SinDDM/models.py:63-64 for l1
+// 27 MACs per output: nothing for the matrix cores to amortise (the implicit-GEMM kernel padded K from 27 to 72 and
+// was store-issue bound at 1.6 TB/s).  VALU kernel: a thread owns one pixel, keeps its 3x3x3 patch in registers
+// and walks the output channels with the weights as SCALAR operands (the channel index is wave-uniform, so the
+// compiler fetches them with s_load through the scalar cache); every store is 64 consecutive floats of one channel.
+// Write-bound: 4*C_out bytes per pixel.  (Two pixels per thread with packed FMAs measured 19 % slower.)
+// =====================================================================================
+__global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              float* __restrict__ out_pre, int H, int W, int Cout) {
+    const int HW = H * W;
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool live = p < HW;
+    const int pc = live ? p : HW - 1;
+    const int y = pc / W, x = pc - y * W;
+    const float* src = in + (size_t)b * 3 * HW;
+    float v[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int gy = y + ky - 1, gx = x + kx - 1;
+                const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                v[ci * 9 + ky * 3 + kx] = ok ? src[(size_t)ci * HW + (size_t)gy * W + gx] : 0.0f;
+            }
+    float* dst = out + (size_t)b * Cout * HW + pc;
+    float* dpre = out_pre ? out_pre + (size_t)b * Cout * HW + pc : nullptr;
+#pragma unroll 4
+    for (int co = 0; co < Cout; ++co) {
+        const float* wc = w + co * 27;          // wave-uniform -> scalar loads
+        float acc = bias[co];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc = fmaf(v[k], wc[k], acc);
+        if (live) {
+            if (dpre) dpre[(size_t)co * HW] = acc;
+            dst[(size_t)co * HW] = gelu_erf(acc);
+        }
+    }
+}
+
+// =====================================================================================
 // final 1x1 conv (half -> 3)                      reference SinDDM/models.py:130-132,151
 // =====================================================================================
 __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ a, const float* __restrict__ w,
@@ -515,9 +559,16 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
         c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
+        static const int c3 = getenv("SINDDM_CONV_C3") ? atoi(getenv("SINDDM_CONV_C3")) : 1;
         if (wino && b.pk_wc1 >= 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);
+        } else if (b.cin == 3 && c3) {
+            // C_in = 3: dedicated VALU kernel straight from the PyTorch-layout weights
+            hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, hbuf,
+                               params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout);
+            SINDDM_LAUNCH_CHECK();
+            rc = 0;
         } else {
             c1.w3 = packed + b.pk_c1; c1.nch3 = b.nch1;
             rc = conv_launch(c1, b.mt, st);
