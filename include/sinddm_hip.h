@@ -63,6 +63,16 @@ int sinddm_net_forward(const float* params, const float* packed, const float* x,
                        const int64_t* t_dev, int t_host, float scale, float* out,
                        int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
+/* The conditioning path alone: SinusoidalPosEmb(32) of t and of the scale, time_mlp, and every block's
+ * time_reshape(mlp(GELU(cond)))            reference SinDDM/models.py:39-46,106-110,136-141 and :54-60,74-76.
+ *   emb_out        (B,64)  [sin(t f)|cos(t f)|sin(s f)|cos(s f)]   or NULL
+ *   cond_vec_out   (B,32)  time_mlp output                         or NULL
+ *   block_bias_out (B,sinddm_cond_stride(dim)) per-sample bias each block adds after its depthwise conv
+ *                  (l1: 3 | l2: dim/2 | l3: dim | l4: dim channels, concatenated)                          */
+int sinddm_cond_embed(const float* params, const int64_t* t_dev, int t_host, float scale, int dim, int B,
+                      float* emb_out, float* cond_vec_out, float* block_bias_out, void* stream);
+int sinddm_cond_stride(int dim);
+
 /* ---- diffusion elementwise --------------------------------------------------------------- */
 /* out = sqrt_ac[t]*x0 + sqrt_1m_ac[t]*noise      reference SinDDM/models.py:570-576 (+extract,
  * functions.py:105-108).  If x_orig != NULL the training-time blur mix of models.py:583-585 is

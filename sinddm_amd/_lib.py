@@ -21,6 +21,7 @@ ABI_SYMBOLS = (
     "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2", "sinddm_prof_end3",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
+    "sinddm_cond_embed", "sinddm_cond_stride",
 )
 
 
@@ -61,6 +62,8 @@ def load() -> C.CDLL:
         "sinddm_workspace_bytes": (sz, [i, i, i, i]),
         "sinddm_pack_weights": (i, [p, p, i, p]),
         "sinddm_net_forward": (i, [p, p, p, p, i, f, p, i, i, i, i, p, sz, p]),
+        "sinddm_cond_embed": (i, [p, p, i, f, i, i, p, p, p, p]),
+        "sinddm_cond_stride": (i, [i]),
         "sinddm_q_sample": (i, [p, p, p, p, p, p, p, p, i, i, i64, p]),
         "sinddm_reverse_step": (i, [p, p, p, p, p, C.POINTER(StepCoefs), i64, p]),
         "sinddm_reverse_step_edit": (i, [p, p, p, p, p, C.POINTER(StepCoefs), p, p, i, i, i, p]),

@@ -653,6 +653,28 @@ int sinddm_net_forward(const float* params, const float* packed, const float* x,
                             static_cast<hipStream_t>(stream), nullptr);
 }
 
+int sinddm_cond_embed(const float* params, const int64_t* t_dev, int t_host, float scale, int dim, int B,
+                      float* emb_out, float* cond_vec_out, float* block_bias_out, void* stream) {
+    if (!params || !block_bias_out || B <= 0) return SINDDM_E_BADARG;
+    NetPlan P = make_plan(dim);
+    if (!P.ok) return SINDDM_E_BADSHAPE;
+    CondArgs ca{};
+    ca.params = params; ca.t_dev = reinterpret_cast<const long long*>(t_dev); ca.t_host = t_host; ca.scale = scale;
+    ca.out = block_bias_out; ca.cond_stride = P.cond_stride;
+    ca.tm0_w = P.tm0_w; ca.tm0_b = P.tm0_b; ca.tm2_w = P.tm2_w; ca.tm2_b = P.tm2_b;
+    for (int l = 0; l < 4; ++l) {
+        ca.mlp_w[l] = P.blk[l].mlp_w; ca.mlp_b[l] = P.blk[l].mlp_b;
+        ca.tr_w[l] = P.blk[l].tr_w; ca.tr_b[l] = P.blk[l].tr_b;
+        ca.cin[l] = P.blk[l].cin; ca.coff[l] = P.blk[l].cond_off;
+    }
+    ca.cond_vec = cond_vec_out; ca.emb_out = emb_out;
+    hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(128), 0, static_cast<hipStream_t>(stream), ca);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_cond_stride(int dim) { NetPlan p = make_plan(dim); return p.ok ? p.cond_stride : -1; }
+
 int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, float* out, const float* tab_sqrt_ac,
                     const float* tab_sqrt_1m_ac, const float* gamma_row, const int64_t* t_dev, int t_host, int B,
                     int64_t n, void* stream) {

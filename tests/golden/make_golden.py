@@ -23,6 +23,7 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   c1_pyramid.npz     the C1 balloons pyramid (uint8 images) the trainer fixtures use
   g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
   g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
+  g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
   g13_roi_i2i.npz    ROI-guided p_sample steps (roi_patch_modification) and an image2image (style-transfer path,
                      no mask / no histogram matching: scikit-image is absent) chain, dim=32, hash noise
 """
@@ -366,6 +367,50 @@ def g9(meta):
          plan_len=np.array(len(plan)), ideal=np.array(ideal))
 
 
+
+def g14():
+    """Full C2 chain: 5 scales, T=1000, B=1, dim=160 = 2 478 chained reference evaluations (the length the
+    headline config runs), hash noise.  Also the chain restarted at every scale from the reference's own previous-scale
+    output (same thing, stored once) and snapshots of the running sample every 250 steps of scale 0."""
+    with open(os.path.join(HERE, "g11_img_scales.json")) as f:
+        c2 = json.load(f)["C2"]
+    net = ref_net(160)
+    sizes = [tuple(s) for s in c2["sizes"]]
+    d = make_diffusion(net, sizes, c2["rescale_losses"], c2["scale_factor"], c2["n_scales"], c2["T"])
+    ideal = d.num_timesteps_ideal
+    assert ideal == c2["num_timesteps_ideal"]
+    plan = [("init", 0, 0)] + [("step", 0, t) for t in reversed(range(c2["T"]))]
+    for s in range(1, c2["n_scales"]):
+        plan += [("renoise", s, 0)] + [("step", s, t) for t in reversed(range(ideal[s]))]
+    feeder = NoiseFeeder(plan)
+    snaps = {}
+    o_ps = d.p_sample
+
+    def rec_p_sample(x, t, s, *a, **k):
+        y = o_ps(x, t, s, *a, **k)
+        ti = int(t[0])
+        if ti % 250 == 0:
+            snaps[f"snap_s{int(s)}_t{ti}"] = y.detach().clone()
+        return y
+
+    d.p_sample = rec_p_sample
+    outs = []
+    import time
+    t0 = time.time()
+    with patched_noise(feeder), torch.no_grad():
+        img = d.sample(batch_size=1, s=0)
+        outs.append(img)
+        print("g14 scale 0 done", time.time() - t0, flush=True)
+        for s in range(1, c2["n_scales"]):
+            img = d.sample_via_scale(1, outs[-1], s=s, scale_mul=(1, 1), custom_sample=True,
+                                     custom_img_size_idx=s, custom_t=ideal[1:][s - 1])
+            outs.append(img)
+            print("g14 scale", s, "done", time.time() - t0, flush=True)
+    assert feeder.i == len(plan), (feeder.i, len(plan))
+    save("g14_chain_c2.npz", **{f"out_s{i}": o for i, o in enumerate(outs)}, **snaps,
+         plan_len=np.array(len(plan)), ideal=np.array(ideal))
+
+
 def g10(meta, workdir):
     """20 reference train() steps at dim=32, B=2, with injected (s, t, noise)."""
     c1 = meta["C1"]
@@ -549,6 +594,9 @@ def main():
         finally:
             shutil.rmtree(workdir, ignore_errors=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        g14()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
         try:
@@ -569,6 +617,7 @@ def main():
         g10(meta, workdir)
         g12(workdir)
         g13(workdir)
+        g14()
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

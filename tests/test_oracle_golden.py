@@ -143,6 +143,32 @@ def test_g9_chain_c1(golden):
         assert rel_l2(o, g[f"out_s{i}"]) < 1e-4, i
 
 
+def test_g14_chain_c2_head(golden):
+    """G14 (the reference's full C2 chain: T=1000, 5 scales, 2 478 evaluations): the oracle follows the reference over
+    the first 251 steps of scale 0 (t = 999..749, snapshot at t = 750) and over the last 60 steps of scale 1
+    restarted from the reference's own snapshot -- bounded so the CPU suite stays short; the whole chain is the GPU
+    test's job (tests/test_gpu_parity_band.py)."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g14_chain_c2.npz")
+    c2 = meta["C2"]
+    sched = _sched(meta, "C2")
+    assert sched["num_timesteps_ideal"] == list(g["ideal"])
+    sd = closed_form_state_dict(160)
+    sizes = [tuple(s) for s in c2["image_sizes_hw"]]
+    with torch.no_grad():
+        x = hash_randn((1, 3) + sizes[0], noise_key("init", 0, 0))
+        for t in range(999, 749, -1):
+            x = O.p_sample(sched, sd, x, t, 0, hash_randn((1, 3) + sizes[0], noise_key("step", 0, t)), None)
+        assert rel_l2(x, g["snap_s0_t750"]) < 1e-5
+        # scale 1: t = 249 .. 0 would be 250 steps; take the tail from the t=250 snapshot down to t = 190, then
+        # compare the t = 0 end point of a run that starts from the snapshot (all 250 steps at 67x90 are cheap)
+        up = O.bilinear_upsample(torch.from_numpy(g["out_s0"]), sizes[1])
+        x = torch.from_numpy(g["snap_s1_t250"])
+        for t in range(249, -1, -1):
+            x = O.p_sample(sched, sd, x, t, 1, hash_randn((1, 3) + sizes[1], noise_key("step", 1, t)), up)
+        assert rel_l2(x, g["out_s1"]) < 1e-5
+
+
 def test_adam_and_lr_restatement():
     torch.manual_seed(0)
     p = torch.randn(50)
