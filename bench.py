@@ -3,18 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Headline metric (BASELINE.json): diffusion steps/sec at the finest scale, on config C2 (balloons,
-5-scale pyramid, T=1000, batch 16 per GPU, finest scale 186x248, dim=160, fp32, synthetic closed-form
-weights, torch.randn noise).  One "step" = one reverse diffusion step (p_sample: SinDDMNet forward +
-fused reverse-step kernel + noise draw) for the whole per-GPU batch.  `value` = sample-steps/s
-summed over all ranks (weak scaling: every rank runs its own 16 independent chains, no data-path
-collective).  The second half of the metric, images/s of a FULL multi-scale sample (all 5 scales,
-2478 network evaluations per image, RCCL all-gather of the results at the end), is measured once
-after the timed region and reported as `full_sample` in the same JSON line.
+Metric (BASELINE.json): diffusion steps/sec at the finest scale + images/sec of a full multi-scale sample.
+One "step" = one reverse diffusion step (p_sample: SinDDMNet forward + fused reverse-step kernel + noise draw) for
+the whole per-GPU batch at the finest pyramid scale.  `value` = sample-steps/s summed over all ranks (weak scaling:
+every rank runs its own independent chains, no data-path collective; the only collective is the all-gather of the
+finished images in the full-sample leg).
 
-Also in the line: `roofline` for the dominant kernel (the fp32-MFMA implicit-GEMM conv, measured with
-HIP events around every conv launch of the timed region, on the stream they are launched on) and
-`cpu_baseline` (the oracle's CPU restatement of the same step, timed on the host cores, rank 0, N=1).
+Default workload at N=1: **C3** (seascape 6-scale pyramid, T=1000, finest scale 411x512, batch 64 -- the largest
+single-GPU configuration of BASELINE.json, its "roofline run").  The C2 record (balloons 5 scales, 186x248, batch 16;
+the round-1 headline) is measured right after it and nested in the same JSON line under "c2", the training step
+(SURVEY 8(d) secondary metric: batch 32 at the C2 finest scale, forward + backward + fused Adam) under "train".
+
+`roofline` describes the dominant kernel (conv_wino_kernel: Winograd F(2x2,3x3) 3x3 convolution on the fp32 matrix
+cores): `achieved` = the FLOPs the matrix pipe has to retire for the algorithmic work of a launch (16/36 of the
+direct-convolution FLOPs 2*9*Cin*Cout per pixel; padded tiles and everything else the kernel does are NOT counted)
+divided by the average launch time measured with HIP events around every launch inside the timed region;
+`frac` = achieved / 157.3 TF/s (<= 1 by construction).  The Winograd saving is reported separately
+(`algorithmic_tflops`, `algorithmic_speedup`).  `cpu_baseline` = the oracle's CPU restatement of the same step.
+
+`--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with N ranks
+(one per GPU, RCCL) and fails if the node has fewer than N devices.
 """
 from __future__ import annotations
 
@@ -22,6 +30,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -30,219 +39,352 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 rate)
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32 rate at 2.4 GHz)
+HBM_PEAK_GBS = 8000.0              # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured achievable)
 NET_FLOP_PER_PIXEL = 2_150_230     # one SinDDMNet forward, per pixel per sample
+WINO_FLOP_PER_PIXEL = 2 * 9 * 115_200   # the seven 3x3 convs the Winograd kernel runs (direct-conv count)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2")
-    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the config's batch)")
-    ap.add_argument("--no-full", action="store_true", help="skip the full multi-scale sample leg")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3", help="headline workload (C3 = largest 1-GPU config of BASELINE.json)")
+    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the config's per-GPU batch)")
+    ap.add_argument("--no-full", action="store_true", help="skip the full multi-scale sample legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-c2", action="store_true", help="skip the nested C2 record")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
     ap.add_argument("--seed", type=int, default=1234)
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch.distributed as td
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the hot path exists)")
-    # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): SINDDM_BENCH_BACKEND=gloo stages the tiny timing
-    # collectives through the host and SINDDM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0; production = nccl/RCCL
-    backend = os.environ.get("SINDDM_BENCH_BACKEND", "nccl")
-    if os.environ.get("SINDDM_BENCH_ONE_DEVICE", "0") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            td.init_process_group(backend="nccl", device_id=dev)
-        else:
-            td.init_process_group(backend=backend)
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    def allreduce_max(t):
-        if world > 1:
-            if backend == "nccl":
-                td.all_reduce(t, op=td.ReduceOp.MAX)
+
+def _respawn(args):
+    """`python bench.py --gpus N` outside torchrun: become N ranks (one per GPU)."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get("SINDDM_BENCH_ONE_DEVICE", "0") != "1":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes only {have} GPU(s)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Ctx:
+    """Rank / device / collective plumbing."""
+
+    def __init__(self, args):
+        import torch.distributed as td
+        self.td = td
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"launched with WORLD_SIZE={self.world} but --gpus {args.gpus}")
+        # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): SINDDM_BENCH_BACKEND=gloo stages the timing
+        # collectives through the host and SINDDM_BENCH_ONE_DEVICE=1 puts every rank on cuda:0; production = RCCL
+        self.backend = os.environ.get("SINDDM_BENCH_BACKEND", "nccl")
+        if os.environ.get("SINDDM_BENCH_ONE_DEVICE", "0") == "1":
+            local_rank = 0
+        elif torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {self.rank}: no device {local_rank} (device_count={torch.cuda.device_count()})")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.comm_world = 1
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                td.init_process_group(backend="nccl", device_id=self.dev)
             else:
-                h = t.cpu()
-                td.all_reduce(h, op=td.ReduceOp.MAX)
-                t.copy_(h)
-        return t
-    assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+                td.init_process_group(backend=self.backend)
+            self.comm_world = td.get_world_size()
+            assert self.comm_world == self.world
 
+    def barrier(self):
+        if self.world > 1:
+            self.td.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t)
+
+    def gather(self, cur, B):
+        if self.world == 1:
+            return cur
+        if self.backend == "nccl":
+            out = torch.empty((self.world * B,) + tuple(cur.shape[1:]), device=self.dev)
+            self.td.all_gather_into_tensor(out, cur.contiguous())
+            return out
+        from sinddm_amd import dist as sdist
+        return sdist.gather_batch(cur.cpu(), self.world * B).to(self.dev)
+
+
+def _prof(lib, kind, reset):
     from sinddm_amd import _lib
+    ms, n, fl, ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    _lib.check(lib.sinddm_prof_end3(kind, C.byref(ms), C.byref(n), C.byref(fl), C.byref(ex), reset), "sinddm_prof_end3")
+    return ms.value, n.value, fl.value, ex.value
+
+
+def _traffic(cfg_name):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (profiles/traffic.json), or None."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        return t.get(cfg_name, {}).get("conv_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
+    """Finest-scale reverse steps of one config: the timed region + the roofline of the dominant kernel."""
     from sinddm_amd.configs import CONFIGS, build_diffusion
-    lib = _lib.load()
-    cfg = CONFIGS[args.config]
-    B = args.batch or (cfg["batch"] if args.config in ("C1", "C2", "C3") else max(1, cfg["batch"] // 8))
-    torch.manual_seed(args.seed + rank)
-    net, d = build_diffusion(args.config, dim=160, device=dev)
+    cfg = CONFIGS[cfg_name]
+    torch.manual_seed(seed + ctx.rank)
+    net, d = build_diffusion(cfg_name, dim=160, device=ctx.dev)
     n_scales = len(cfg["sizes"])
     s = n_scales - 1
     mul = cfg.get("scale_mul", (1, 1))
     H, W = d.target_size(s, mul, True, s)
     total_t = d.num_timesteps_ideal[s]
-
     # state of a chain that has just arrived at the finest scale
-    x_tilde = torch.randn(B, 3, H, W, device=dev).clamp_(-1, 1)
+    x_tilde = torch.randn(B, 3, H, W, device=ctx.dev).clamp_(-1, 1)
     d.img_prev_upsample = x_tilde
     img = d._q_sample_impl(x_tilde, None, total_t, torch.randn_like(x_tilde))
-    t_seq = [(total_t - 1 - i) % total_t for i in range(args.warmup + args.steps)]
-
-    def barrier():
-        if world > 1:
-            td.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
+    t_seq = [(total_t - 1 - i) % total_t for i in range(warmup + steps)]
+    for i in range(warmup):
         img = d._p_sample_host_t(img, t_seq[i], s)
-    barrier()
+    ctx.barrier()
     lib.sinddm_prof_begin()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(warmup, warmup + steps):
         img = d._p_sample_host_t(img, t_seq[i], s)
-    barrier()
+    ctx.barrier()
     dt = time.perf_counter() - t0
-    def prof(kind, reset):
-        ms, n, fl, ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        _lib.check(lib.sinddm_prof_end3(kind, C.byref(ms), C.byref(n), C.byref(fl), C.byref(ex), reset), "sinddm_prof_end3")
-        return ms.value, n.value, fl.value, ex.value
-
-    wino = os.environ.get("SINDDM_CONV_WINO", "1") != "0"
-    dom_ms, dom_n, dom_fl, dom_ex = prof(1 if wino else 3, 0)        # the dominant kernel family only
-    all_ms, all_n, all_fl, all_ex = prof(0, 1)                      # every MFMA convolution of the step
-    tt = allreduce_max(torch.tensor([dt], device=dev, dtype=torch.float64))
-    dt = float(tt)
+    dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
+    all_ms, all_n, all_fl, all_ex = _prof(lib, 0, 1)          # every MFMA convolution of the step
+    dt = ctx.max_over_ranks(dt)
     assert torch.isfinite(img).all()
-
-    ms_per_step = dt / args.steps * 1e3
-    value = world * B * args.steps / dt
-
-    # ---- roofline of the dominant kernel ----
-    # achieved = ALGORITHMIC FLOPs per launch (direct-convolution count 2*9*Cin*Cout per pixel of the layers this
-    # kernel runs; the Winograd kernel executes 16/36 of them) / its average launch duration, measured with HIP events
-    # around every launch on the launch stream inside the timed region.  The same kernel's average duration in
-    # profiles/*_bench_kernel_stats.txt (rocprofv3 --kernel-trace --stats) must agree with avg_launch_ms.
     px = B * H * W
     avg_launch_ms = dom_ms / max(1, dom_n)
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    algorithmic = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_ex / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("conv_bytes_per_launch")   # PMC passes, profiles/r01k_pmc_summary.txt
-        except Exception:
-            traffic = None
-    roofline = {"bound": "mfma",
-                "kernel": ("conv_wino_kernel<5,3,*> (Winograd F(2x2,3x3) 3x3 conv on fp32 v_mfma_f32_16x16x4_f32; 7 launches "
-                           "per step)" if wino else
-                           "conv_mfma_dma_kernel<5,2,0,8> (fp32 v_mfma_f32_16x16x4_f32 implicit-GEMM 3x3 conv)"),
-                "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "algorithmic_flops_per_launch": round(dom_fl / max(1, dom_n)),
-                "executed_tflops": round(executed, 2), "executed_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-                "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(dom_n),
-                "share_of_step": round(dom_ms / (dt * 1e3), 4),
-                "all_mfma_convs": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
-                                   "launches": int(all_n), "share_of_step": round(all_ms / (dt * 1e3), 4)},
-                "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * args.steps / dt / 1e12, 2)}
+    traffic = _traffic(cfg_name)
+    roofline = {
+        "bound": "mfma",
+        "kernel": "conv_wino_kernel<5,3,*> (Winograd F(2x2,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32; 7 launches per step)",
+        "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+        "traffic": traffic,
+        "hbm_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                     if traffic and avg_launch_ms > 0 else None),
+        "flops_counted": "16/36 of the direct-conv FLOPs of the launch (what F(2x2,3x3) must multiply); padding excluded",
+        "executed_flops_per_launch": round(dom_ex / max(1, dom_n)),
+        "algorithmic_flops_per_launch": round(dom_fl / max(1, dom_n)),
+        "algorithmic_tflops": round(algorithmic, 2), "algorithmic_speedup": 2.25,
+        "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(dom_n),
+        "share_of_step": round(dom_ms / (dt * 1e3), 4),
+        "all_mfma_convs": {"algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
+                           "launches": int(all_n), "share_of_step": round(all_ms / (dt * 1e3), 4)},
+        "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * steps / dt / 1e12, 2),
+    }
+    rec = {"workload": f"{cfg_name}: {n_scales}-scale pyramid, T={cfg['T']}, finest scale {H}x{W}, batch {B} per GPU, dim=160",
+           "value": round(ctx.world * B * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4),
+           "steps_per_sec_per_gpu": round(steps / dt, 4), "batch_per_gpu": B, "finest_hw": [H, W], "scale": s,
+           "roofline": roofline}
+    return rec, (net, d, cfg, H, W, s, total_t)
 
-    # ---- second half of the metric: one FULL multi-scale sample (all scales + all-gather) ----
-    full = None
-    if not args.no_full:
-        barrier()
-        t0 = time.perf_counter()
-        cur = d.sample(batch_size=B, scale_0_size=d.target_size(0, mul, True, 0), s=0)
-        for si in range(1, n_scales):
-            cur = d.sample_via_scale(B, cur, s=si, scale_mul=mul, custom_sample=True, custom_img_size_idx=si,
-                                     custom_t=d.num_timesteps_ideal[si])
-        if world > 1:
-            from sinddm_amd import dist as sdist
-            if backend == "nccl":
-                out = torch.empty((world * B,) + tuple(cur.shape[1:]), device=dev)
-                td.all_gather_into_tensor(out, cur.contiguous())
-                cur = out
-            else:
-                cur = sdist.gather_batch(cur.cpu(), world * B).to(dev)
-        barrier()
-        ft = float(allreduce_max(torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)))
-        evals = sum(d.num_timesteps_ideal)
-        pix_steps = 0
-        for si in range(n_scales):
-            h, w = d.target_size(si, mul, True, si)
-            pix_steps += h * w * d.num_timesteps_ideal[si]
-        full = {"imgs_per_sec": round(world * B / ft, 4), "seconds": round(ft, 3), "images": world * B,
-                "net_evals_per_image": evals,
-                "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * B * world / ft / 1e12, 2),
-                "finite": bool(torch.isfinite(cur).all())}
 
-    # ---- CPU baseline: the oracle's restatement of the same step on the host cores ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        from oracle import sinddm_oracle as O
-        from sinddm_amd.synth import closed_form_state_dict
-        ncpu = os.cpu_count() or 1
-        sd = closed_form_state_dict(160)
-        sched = O.make_schedule(cfg["T"], n_scales, cfg["rescale_losses"], 1, train_full_t=True)
-        # pick the thread count that is actually fastest for this op mix (oneDNN convs stop scaling long before
-        # 256 threads): a short calibration on a small image, then the measurement with the winner
-        cands = sorted({ncpu, min(ncpu, 64), min(ncpu, 32)})
-        best, cores = None, ncpu
-        xs = torch.randn(1, 3, 94, 126)
-        for nthr in cands:
-            torch.set_num_threads(nthr)
-            with torch.no_grad():
-                O.net_forward(sd, xs, torch.tensor([5]), 2)
-                t0 = time.perf_counter()
-                O.net_forward(sd, xs, torch.tensor([5]), 2)
-                dtc = time.perf_counter() - t0
-            if best is None or dtc < best:
-                best, cores = dtc, nthr
-        torch.set_num_threads(cores)
-        cb = min(B, 4)
-        xc = torch.randn(cb, 3, H, W)
-        xt = torch.randn(cb, 3, H, W)
-        zc = torch.randn(cb, 3, H, W)
+def elementwise_leg(d, B, H, W, s, total_t, dev):
+    """GB/s of the HBM-bound sampler kernels at the finest scale (algorithmic bytes of SURVEY 8(d) / HIP-event time
+    on the launch stream = torch's current stream)."""
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    n = B * 3 * H * W
+    x, e, z = (torch.randn(B, 3, H, W, device=dev) for _ in range(3))
+    xt = d.img_prev_upsample
+    out = torch.empty_like(x)
+    k = d.step_coefs(total_t - 1, s, True)
+    st = _lib.stream_ptr(dev)
+
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    res = {}
+    t = timed(lambda: lib.sinddm_reverse_step(_lib.ptr(x), _lib.ptr(e), _lib.ptr(xt), _lib.ptr(z), _lib.ptr(out),
+                                              C.byref(k), n, st))
+    res["reverse_step"] = {"bytes_per_elem": 20, "GBps": round(20 * n / t / 1e9, 1), "us": round(t * 1e6, 2)}
+    t = timed(lambda: lib.sinddm_q_sample(_lib.ptr(x), None, _lib.ptr(z), _lib.ptr(out),
+                                          _lib.ptr(d.sqrt_alphas_cumprod), _lib.ptr(d.sqrt_one_minus_alphas_cumprod),
+                                          None, None, total_t, B, n // B, st))
+    res["q_sample"] = {"bytes_per_elem": 12, "GBps": round(12 * n / t / 1e9, 1), "us": round(t * 1e6, 2)}
+    for v in res.values():
+        v["hbm_frac"] = round(v["GBps"] / HBM_PEAK_GBS, 4)
+    return res
+
+
+def full_sample_leg(ctx, d, cfg, B):
+    """One FULL multi-scale sample (all scales, upsample + re-noise between them, all-gather of the results)."""
+    n_scales = len(cfg["sizes"])
+    mul = cfg.get("scale_mul", (1, 1))
+    ctx.barrier()
+    t0 = time.perf_counter()
+    cur = d.sample(batch_size=B, scale_0_size=d.target_size(0, mul, True, 0), s=0)
+    for si in range(1, n_scales):
+        cur = d.sample_via_scale(B, cur, s=si, scale_mul=mul, custom_sample=True, custom_img_size_idx=si,
+                                 custom_t=d.num_timesteps_ideal[si])
+    cur = ctx.gather(cur, B)
+    ctx.barrier()
+    ft = ctx.max_over_ranks(time.perf_counter() - t0)
+    pix_steps = 0
+    for si in range(n_scales):
+        h, w = d.target_size(si, mul, True, si)
+        pix_steps += h * w * d.num_timesteps_ideal[si]
+    return {"imgs_per_sec": round(ctx.world * B / ft, 4), "seconds": round(ft, 3), "images": ctx.world * B,
+            "net_evals_per_image": sum(d.num_timesteps_ideal),
+            "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * B * ctx.world / ft / 1e12, 2),
+            "finite": bool(torch.isfinite(cur).all())}
+
+
+def train_leg(ctx, steps=5, warmup=2):
+    """SURVEY 8(d) secondary metric: train() steps/s at batch 32 on the C2 finest scale (forward + backward + fused
+    Adam; reference trainer.py:194-213 with gradient_accumulate_every=1)."""
+    from sinddm_amd.configs import build_diffusion
+    from sinddm_amd.optim import FusedAdam
+    net, d = build_diffusion("C2", 160, ctx.dev)
+    opt = FusedAdam(net, lr=1e-3)
+    s = len(d.image_sizes) - 1
+    H, W = d.image_sizes[s]
+    img = torch.randn(32, 3, H, W, device=ctx.dev).clamp(-1, 1)
+    data = (img, img.clone())
+
+    def one():
+        loss = d(data, s)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"C2 finest scale {H}x{W}, batch 32, dim=160: p_losses forward + backward + fused Adam",
+            "ms_per_step": round(dt * 1e3, 2), "steps_per_sec": round(1 / dt, 3),
+            "net_tflops_3x_forward": round(3 * NET_FLOP_PER_PIXEL * 32 * H * W / dt / 1e12, 1),
+            "loss_finite": bool(torch.isfinite(loss))}
+
+
+def cpu_leg(cfg, n_scales, B, H, W, s, total_t):
+    """The oracle's restatement of the same finest-scale step on the host cores (bounded sample, ~10-20 s)."""
+    from oracle import sinddm_oracle as O
+    from sinddm_amd.synth import closed_form_state_dict
+    ncpu = os.cpu_count() or 1
+    sd = closed_form_state_dict(160)
+    sched = O.make_schedule(cfg["T"], n_scales, cfg["rescale_losses"], 1, train_full_t=True)
+    # pick the thread count that is actually fastest for this op mix (oneDNN convs stop scaling long before
+    # 256 threads): a short calibration on a small image, then the measurement with the winner
+    best, cores = None, ncpu
+    xs = torch.randn(1, 3, 94, 126)
+    for nthr in sorted({ncpu, min(ncpu, 64), min(ncpu, 32)}):
+        torch.set_num_threads(nthr)
         with torch.no_grad():
-            O.p_sample(sched, sd, xc, total_t - 1, s, zc, xt)          # warm
-            n_cpu, t0 = 0, time.perf_counter()
-            while time.perf_counter() - t0 < 10.0 and n_cpu < 50:
-                xc = O.p_sample(sched, sd, xc, total_t - 2 - n_cpu, s, zc, xt)
-                n_cpu += 1
-            ct = time.perf_counter() - t0
-        cpu = {"value": round(cb * n_cpu / ct, 3), "unit": "sample-steps/s", "cores": cores, "kind": "port",
-               "sample": f"{n_cpu} finest-scale p_sample steps of batch {cb} at {H}x{W} "
-                         f"(oracle/sinddm_oracle.py, torch CPU fp32, {cores} threads)"}
+            O.net_forward(sd, xs, torch.tensor([5]), 2)
+            t0 = time.perf_counter()
+            O.net_forward(sd, xs, torch.tensor([5]), 2)
+            dtc = time.perf_counter() - t0
+        if best is None or dtc < best:
+            best, cores = dtc, nthr
+    torch.set_num_threads(cores)
+    cb = 1 if H * W > 100_000 else min(B, 4)
+    xc, xt, zc = (torch.randn(cb, 3, H, W) for _ in range(3))
+    with torch.no_grad():
+        O.p_sample(sched, sd, xc, total_t - 1, s, zc, xt)          # warm
+        n_cpu, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 12.0 and n_cpu < 50:
+            xc = O.p_sample(sched, sd, xc, total_t - 2 - n_cpu, s, zc, xt)
+            n_cpu += 1
+        ct = time.perf_counter() - t0
+    return {"value": round(cb * n_cpu / ct, 3), "unit": "sample-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_cpu} finest-scale p_sample steps of batch {cb} at {H}x{W} "
+                      f"(oracle/sinddm_oracle.py, torch CPU fp32, {cores} threads)"}
 
-    if rank == 0:
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback of the hot path exists)")
+    ctx = Ctx(args)
+    from sinddm_amd import _lib
+    from sinddm_amd.configs import CONFIGS
+    lib = _lib.load()
+
+    def per_gpu_batch(name):
+        c = CONFIGS[name]
+        return c["batch"] if name in ("C1", "C2", "C3") else max(1, c["batch"] // 8)   # C4/C5 are 8-GPU configs
+
+    B = args.batch or per_gpu_batch(args.config)
+    head, (net, d, cfg, H, W, s, total_t) = steps_leg(ctx, lib, args.config, B, args.steps, args.warmup, args.seed)
+    head["elementwise"] = elementwise_leg(d, B, H, W, s, total_t, ctx.dev)
+    full = None if args.no_full else full_sample_leg(ctx, d, cfg, B)
+    cpu = None
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu:
+        cpu = cpu_leg(cfg, len(cfg["sizes"]), B, H, W, s, total_t)
+    del net, d
+    torch.cuda.empty_cache()
+
+    c2 = None
+    if args.config != "C2" and not args.no_c2:
+        c2, (net2, d2, cfg2, H2, W2, s2, tt2) = steps_leg(ctx, lib, "C2", per_gpu_batch("C2"), 20, 3, args.seed)
+        c2["elementwise"] = elementwise_leg(d2, per_gpu_batch("C2"), H2, W2, s2, tt2, ctx.dev)
+        if not args.no_full:
+            c2["full_sample"] = full_sample_leg(ctx, d2, cfg2, per_gpu_batch("C2"))
+        c2["unit"] = "sample-steps/s (finest scale, batch x steps/s, all GPUs)"
+        del net2, d2
+        torch.cuda.empty_cache()
+    train = None
+    if ctx.rank == 0 and ctx.world == 1 and not args.no_train:
+        train = train_leg(ctx)
+
+    if ctx.rank == 0:
         line = {
             "metric": "diffusion steps/sec (finest scale) + imgs/sec full multi-scale sample, 1/2/4/8 GPU",
-            "value": round(value, 3), "unit": "sample-steps/s (finest scale, batch x steps/s, all GPUs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "steps_per_sec_per_gpu": round(args.steps / dt, 4),
+            "value": head["value"], "unit": "sample-steps/s (finest scale, batch x steps/s, all GPUs)",
+            "n_gpus": ctx.world, "comm_world_size": ctx.comm_world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "steps_per_sec_per_gpu": head["steps_per_sec_per_gpu"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (closed-form weights of the dim=160 architecture, torch.randn noise/images)",
-            "config": {"workload": f"{args.config}: balloons 5-scale pyramid, T=1000, finest scale {H}x{W}, "
-                                   f"batch {B} per GPU, dim=160" if args.config == "C2" else
-                                   f"{args.config}: finest scale {H}x{W}, T={cfg['T']}, batch {B} per GPU, dim=160",
-                       "batch_per_gpu": B, "global_batch": B * world, "finest_hw": [H, W], "scale": s,
-                       "parallelism": f"independent chains x{world}"},
-            "full_sample": full, "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": B * ctx.world,
+                       "finest_hw": [H, W], "scale": s, "parallelism": f"independent chains x{ctx.world}"},
+            "full_sample": full, "roofline": head["roofline"], "elementwise": head["elementwise"],
+            "cpu_baseline": cpu, "c2": c2, "train": train,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        td.destroy_process_group()
+    if ctx.world > 1:
+        ctx.td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -62,6 +62,7 @@ def build_parser():
 def main():
     args = build_parser().parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    td = None
     if world > 1:
         import torch.distributed as td
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -72,13 +73,27 @@ def main():
         torch.manual_seed(1234 + td.get_rank())      # every rank draws its own chains
     print('num devices: ' + str(torch.cuda.device_count()))
     device = f"cuda:{args.device_num}"
+    if world == 1 and torch.cuda.is_available():
+        torch.cuda.set_device(args.device_num)      # the HIP library launches on the CURRENT device's stream
     scale_mul = (args.scale_mul[0], args.scale_mul[1])
     sched_milestones = [val * 1000 for val in args.sched_k_milestones]
     results_folder = args.results_folder + '/' + args.scope
 
-    sizes, rescale_losses, scale_factor, n_scales = create_img_scales(
-        args.dataset_folder, args.image_name, scale_factor=args.scale_factor, create=True,
-        auto_scale=50000)                                               # reference main.py:71-75
+    # reference main.py:71-75.  Under torch.distributed only rank 0 writes the scale_i/ PNG pyramid; the others wait
+    # and then only derive the sizes / losses from the files rank 0 wrote (create=False), so no rank ever opens a
+    # half-written PNG.
+    rank = 0
+    if world > 1:
+        rank = td.get_rank()
+    if rank == 0:
+        sizes, rescale_losses, scale_factor, n_scales = create_img_scales(
+            args.dataset_folder, args.image_name, scale_factor=args.scale_factor, create=True, auto_scale=50000)
+    if world > 1:
+        td.barrier()
+        if rank != 0:
+            sizes, rescale_losses, scale_factor, n_scales = create_img_scales(
+                args.dataset_folder, args.image_name, scale_factor=args.scale_factor, create=False, auto_scale=50000)
+        td.barrier()
 
     model = SinDDMNet(dim=args.dim, multiscale=True, device=device)
     model.to(device)
@@ -128,7 +143,6 @@ def main():
             f"mode {args.mode!r}: train, sample, style_transfer, harmonization and roi are built for MI355X; the CLIP-guided "
             "modes of the reference need CLIP autograd and are out of scope (SURVEY.md section 8)")
     if world > 1:
-        import torch.distributed as td
         td.destroy_process_group()
 
 

@@ -263,14 +263,17 @@ def p_sample(sched: dict, sd: Dict[str, Tensor], x: Tensor, t: int, s: int, nois
 
 def bilinear_upsample(img: Tensor, size: Tuple[int, int]) -> Tensor:
     """F.interpolate(img, size, mode='bilinear') semantics (align_corners=False, no
-    antialias) as called at models.py:567, written out in fp32 coordinate arithmetic."""
+    antialias) as called at models.py:567, written out in fp32 coordinate arithmetic (source index = one fused
+    multiply-add, like ATen's compiled kernels)."""
     B, C, h, w = img.shape
     H, W = int(size[0]), int(size[1])
 
     def axis(n_in, n_out):
         scale = torch.tensor(n_in / n_out, dtype=torch.float32) if n_out > 0 else torch.tensor(0.0)
         dst = torch.arange(n_out, dtype=torch.float32)
-        src = (scale * (dst + 0.5) - 0.5).clamp(min=0.0)
+        # ATen evaluates scale*(dst+0.5)-0.5 with ONE rounding (the compiler contracts it to an fma, on CPU and GPU
+        # builds alike): pinned by fixture g8:hash_8x776_to_11x1092, where a two-rounding evaluation is 3e-5 off
+        src = (scale.double() * (dst.double() + 0.5) - 0.5).float().clamp(min=0.0)
         i0 = src.floor().to(torch.long).clamp(max=n_in - 1)
         i1 = (i0 + 1).clamp(max=n_in - 1)
         lam = src - i0.to(torch.float32)

@@ -9,6 +9,11 @@ import torch
 from . import _lib
 
 
+# generation counter of the shared training workspace per device: a second training forward before the first
+# backward() would silently overwrite the first graph's saved activations, so backward checks its stamp
+_WS_GEN = {}
+
+
 class _NetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, net, t, scale):
@@ -24,6 +29,9 @@ class _NetTrainFn(torch.autograd.Function):
         _lib.check(lib.sinddm_net_forward_train(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(t),
                                                 0, float(scale), _lib.ptr(out), net.dim, B, H, W, ws.data_ptr(),
                                                 ws.numel(), _lib.stream_ptr(x.device)), "sinddm_net_forward_train")
+        key = ws.data_ptr()
+        _WS_GEN[key] = _WS_GEN.get(key, 0) + 1
+        ctx.ws_gen = (key, _WS_GEN[key])
         ctx.net, ctx.ws, ctx.shape = net, ws, (B, H, W)
         ctx.save_for_backward(x)
         ctx.need_gx = x.requires_grad
@@ -35,6 +43,10 @@ class _NetTrainFn(torch.autograd.Function):
         net = ctx.net
         (x,) = ctx.saved_tensors
         B, H, W = ctx.shape
+        key, gen = ctx.ws_gen
+        if ctx.ws.data_ptr() != key or _WS_GEN.get(key) != gen:
+            raise _lib.SinddmError("the saved activations of this graph were overwritten by a later training forward "
+                                   "(one live SinDDMNet graph per device: call backward() before the next forward)")
         grad_out = grad_out.contiguous()
         gx = torch.empty_like(x) if ctx.need_gx else None
         packed = net.packed_weights()

@@ -479,9 +479,12 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
     if (p >= H * W) return;
     const int oy = p / W, ox = p - oy * W;
     // ATen area_pixel_compute_source_index(align_corners=False): max(scale*(dst+0.5)-0.5, 0), fp32
-    float fy = sy * ((float)oy + 0.5f) - 0.5f;
+    // explicitly ONE rounding (fma), which is what ATen's compiled CPU/GPU kernels do: at source coordinates of
+    // several hundred a two-rounding evaluation moves the interpolation weight by up to an ulp of the coordinate
+    // (3e-5 abs on the 364x1092 scale of config C5; fixture g8:hash_8x776_to_11x1092)
+    float fy = fmaf(sy, (float)oy + 0.5f, -0.5f);
     fy = fy < 0.0f ? 0.0f : fy;
-    float fx = sx * ((float)ox + 0.5f) - 0.5f;
+    float fx = fmaf(sx, (float)ox + 0.5f, -0.5f);
     fx = fx < 0.0f ? 0.0f : fx;
     int iy0 = (int)fy; if (iy0 > h - 1) iy0 = h - 1;
     int ix0 = (int)fx; if (ix0 > w - 1) ix0 = w - 1;

@@ -70,6 +70,7 @@ _WS: Dict[Tuple[str, int], torch.Tensor] = {}
 
 
 def _workspace(device: torch.device, nbytes: int, tag: str = "fwd") -> torch.Tensor:
+    device = torch.device(device)
     key = (tag, device.index if device.index is not None else torch.cuda.current_device())
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:

@@ -43,6 +43,11 @@ def save_image(tensor: torch.Tensor, path: str, nrow: int = 8, padding: int = 2)
         t = t[None]
     t = t.clamp(0, 1)
     B, C, H, W = t.shape
+    if B == 1:
+        # torchvision.utils.make_grid returns a single image as it is: no grid, no 2-pixel frame
+        arr = t[0].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+        Image.fromarray(arr).save(path)
+        return
     ncol = min(nrow, B)
     nrows = (B + ncol - 1) // ncol
     grid = torch.zeros(C, nrows * (H + padding) + padding, ncol * (W + padding) + padding)
@@ -221,7 +226,9 @@ class MultiscaleTrainer(object):
         dp = self.data_parallel
         if dp and self._scale_gen is None:
             self._scale_gen = torch.Generator()
-            self._scale_gen.manual_seed(sdist.broadcast_int(int(torch.seed() % (2 ** 31))))
+            # rank 0's seed, agreed on by broadcast; torch.initial_seed() only READS the global generator, so the
+            # documented per-rank noise streams (manual_seed(1234 + rank) in main.py) stay what the user set
+            self._scale_gen.manual_seed(sdist.broadcast_int(int(torch.initial_seed() % (2 ** 31))))
         net = self.model.denoise_fn
         while self.step < self.train_num_steps:
             s = self._pick_scale(s_weights)
@@ -297,6 +304,9 @@ class MultiscaleTrainer(object):
         t_list = [self.ema_model.num_timesteps_trained[0]] + list(custom_t_list)
         res_sub_folder = '_'.join(str(e) for e in t_list)
 
+        if batch_size < sdist.world_size():
+            raise ValueError(f'sample_scales: batch_size={batch_size} < world_size={sdist.world_size()} would leave ranks '
+                             'without chains (every rank must join the all-gather)')
         local_b = sdist.local_batch(batch_size)          # this rank's independent chains
         is_main = sdist.rank() == 0
         if save_images and is_main:

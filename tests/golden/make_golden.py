@@ -318,6 +318,10 @@ def g8():
                               ((67, 90), (94, 126), 3)):
         x = closed_form_tensor((1, C, h, w), phase=0.9, amp=1.0, freq=0.271)
         out[f"{h}x{w}_to_{H}x{W}"] = F.interpolate(x, size=(H, W), mode="bilinear")
+    # white-noise strip at the source coordinates config C5 reaches (--scale_mul 2 4: 776 -> 1092 columns): one fp32 ulp
+    # of the coordinate is 6e-5 there, which separates a single-rounding (fma) source index from a two-rounding one
+    x = (hash_randn((1, 1, 8, 776), 901) * 0.6).clamp(-1, 1)
+    out["hash_8x776_to_11x1092"] = F.interpolate(x, size=(11, 1092), mode="bilinear")
     save("g8_bilinear.npz", **out)
 
 
@@ -593,6 +597,9 @@ def main():
             g13(workdir)
         finally:
             shutil.rmtree(workdir, ignore_errors=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        g8()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14()

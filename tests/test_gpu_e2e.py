@@ -273,3 +273,25 @@ def test_save_interm_dumps(golden, tmp_path):
     f1 = sorted(os.listdir(tmp_path / "interm" / "interm_samples_scale_1"))
     assert f0 == ["input_noise_s-0.png"] + [f"output_t-{i:03}_s-0.png" for i in range(4)]
     assert f1 == ["noisy_input_s_1.png", "output_t-000_s-1.png", "output_t-001_s-1.png"]
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment re-launches itself as 2 ranks (here: both on
+    the one device, gloo for the timing collectives -- the hooks bench.py documents) and reports n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(SINDDM_BENCH_BACKEND="gloo", SINDDM_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3",
+                        "--warmup", "1", "--no-cpu", "--no-c2", "--no-train"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["comm_world_size"] == 2
+    assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
+    assert line["full_sample"]["images"] == 2 * line["config"]["batch_per_gpu"] and line["full_sample"]["finite"]
+    assert 0 < line["roofline"]["frac"] <= 1.0

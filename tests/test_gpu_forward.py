@@ -99,6 +99,8 @@ def test_upsample_golden(golden):
         x = closed_form_tensor((1, Cc, h, w), phase=0.9, amp=1.0, freq=0.271).to(DEV)
         y = d.upsample(x, (H, W))
         assert max_abs(y.cpu(), g[f"{h}x{w}_to_{H}x{W}"]) < 2e-5
+    x = (hash_randn((1, 1, 8, 776), 901) * 0.6).clamp(-1, 1).to(DEV)      # C5-sized source coordinates, white noise
+    assert max_abs(d.upsample(x, (11, 1092)).cpu(), g["hash_8x776_to_11x1092"]) < 1e-6
 
 
 def test_reverse_step_all_modes_vs_oracle(golden):

@@ -119,7 +119,7 @@ def _scale_entry_and_steps(cfg_name, B, steps_t, check=(0, -1)):
     d.img_prev_upsample = up
     idx = [i % B for i in check]
     up_ref = O.bilinear_upsample(prev[idx], (H, W))
-    assert max_abs(up[idx].cpu(), up_ref) < 2e-5
+    assert max_abs(up[idx].cpu(), up_ref) < 2e-6
     x_ref = O.q_sample(sched, up_ref, torch.full((len(idx),), total_t, dtype=torch.long), nz0[idx])
     assert rel_l2(x[idx].cpu(), x_ref) < 1e-6
     for j, t in enumerate(steps_t):

@@ -182,3 +182,18 @@ def test_train_20_steps_golden(golden, tmp_path):
     moved = float((rp - p0).norm())
     assert float((pv - rp).norm()) / moved < 2e-2, float((pv - rp).norm()) / moved
     assert float((ev - re).norm()) / float((re - p0).norm()) < 2e-2
+
+
+def test_second_forward_before_backward_raises():
+    """The training workspace holds ONE graph's activations; backward of an overwritten graph must fail loudly
+    instead of returning wrong gradients."""
+    from sinddm_amd import _lib
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    x = hash_randn((1, 3, 12, 20), 3).to(DEV)
+    t = torch.tensor([5], device=DEV)
+    y1 = net(x, t, scale=0)
+    y2 = net(x, t, scale=1)
+    y2.sum().backward()
+    with pytest.raises(_lib.SinddmError):
+        y1.sum().backward()

@@ -249,3 +249,18 @@ def test_main_parser_modes():
     assert a.roi_target == [1, 2, 3, 4] and len(a.roi_bbs) == 8
     a = mod.build_parser().parse_args(["--mode", "harmonization"])
     assert a.start_t_harm == 5 and a.start_t_style == 15 and a.harm_mask == "seascape_mask_dragon.png"
+
+
+def test_bench_refuses_missing_gpus():
+    """`python bench.py --gpus N` must become N ranks itself or fail loudly -- never silently run one rank
+    (VERDICT r1 item 1).  Without N devices it exits non-zero and says why."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("SINDDM_BENCH_ONE_DEVICE", None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "9"], capture_output=True,
+                       text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "exposes only" in (r.stderr + r.stdout)

@@ -115,6 +115,9 @@ def test_g8_bilinear(golden):
         x = closed_form_tensor((1, C, h, w), phase=0.9, amp=1.0, freq=0.271)
         y = O.bilinear_upsample(x, (H, W))
         assert max_abs(y, g[f"{h}x{w}_to_{H}x{W}"]) < 2e-6
+    # white noise at the source coordinates config C5 reaches: pins the single-rounding source index
+    x = (hash_randn((1, 1, 8, 776), 901) * 0.6).clamp(-1, 1)
+    assert max_abs(O.bilinear_upsample(x, (11, 1092)), g["hash_8x776_to_11x1092"]) < 1e-6
 
 
 def test_g9_chain_c1(golden):
