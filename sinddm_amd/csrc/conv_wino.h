@@ -21,6 +21,13 @@
 #pragma once
 #include "conv_mfma.h"
 #include "conv1x1.h"
+// SINDDM_WINO_V2 = 1 (default): conv_wino_launch() runs the second-generation kernel of conv_wino2.h (two 4-wave
+// workgroups per CU, wave = frequency row); 0 keeps this file's 16-wave kernel (A/B builds).  The packed weight
+// layout (pack kind 3) follows the same switch.
+#ifndef SINDDM_WINO_V2
+#define SINDDM_WINO_V2 1
+#endif
+#include "conv_wino2.h"
 
 namespace sinddm {
 
@@ -384,6 +391,9 @@ inline int device_cu_count() {
 }
 
 inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
+#if SINDDM_WINO_V2
+    return conv_wino2_launch(a_in, mt, st);
+#endif
     ConvArgs a = a_in;
     const int ntr = wino_ntr();
     ConvProfiler& prof = conv_profiler();

@@ -1,0 +1,608 @@
+// Winograd F(2x2, 3x3) 3x3 convolution on the gfx950 fp32 matrix cores -- second generation ("W4x2").
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 2x2 output tile, d = its 4x4 input patch
+//
+// 16 "frequency" GEMMs  M_ij[co][tile] = sum_ci U_ij[co][ci] * V_ij[ci][tile]  replace the 9-tap implicit GEMM
+// (16 multiplies per 4 outputs instead of 36), all in fp32 on v_mfma_f32_16x16x4_f32.
+//
+// What changed against conv_wino.h (one 16-wave workgroup per CU, wave = one frequency), and why:
+//   * TWO independent 4-wave workgroups per CU (256 registers per wave).  The first-generation kernel kept all 16
+//     waves of a CU in the same phase, so the matrix pipe idled through every output-transform epilogue (15 % of the
+//     launch), every chunk-barrier ramp (7 %) and every item prologue.  Two workgroups drift against each other:
+//     while one is in its epilogue / at a barrier / waiting for its first operands, the other one's wave on the same
+//     SIMD owns the matrix pipe.
+//   * wave i owns the FOUR frequencies (i, 0..3) of a 4x32-pixel tile (2x16 output 2x2-tiles) for MT*16 output
+//     channels: 4 x MT x 2 accumulator tiles (160 registers at MT = 5).  The row half of the input transform
+//     (B^T d) is shared by its four frequencies: per k-step and tile-row TWO 16-byte LDS reads + 8 VALU build four B
+//     operands (the old kernel: 16 four-byte reads + 12 FMAs), and the column half of the OUTPUT transform
+//     (M A) happens in registers, so only 8 instead of 16 values per (channel, tile) cross waves through LDS.
+//   * weights (U, pre-transformed by the pack kernel) are laid out [co-block][16-ch chunk][i][k-step][mt][lane][j]:
+//     ONE 16-byte buffer load per (k-step, mt) brings a lane its four A operands; every load is issued right after
+//     the last MFMA that reads the registers it overwrites, i.e. two k-steps (80 MFMAs) ahead of its use.
+//   * raw input halo tile (16 channels x 6 x 34, plane padded to 256 floats): LDS-DMA, four whole-wave instructions
+//     per channel with per-lane global offsets (hardware bounds check zero-fills halo / missing channels), double
+//     buffered, one 4-wave barrier per 16-channel chunk.
+// Same ConvArgs / epilogue contract as conv_mfma.h (bias, GELU / GELU'(aux) *, identity residual, pre-activation
+// save); 1x1 residual projections are not fused (the caller passes their result as `resid`).
+#pragma once
+#include "conv_mfma.h"
+#include "conv1x1.h"
+
+namespace sinddm {
+
+#ifndef W2_DESYNC
+#define W2_DESYNC 1
+#endif
+#ifndef W2_PIN
+#define W2_PIN 1
+#endif
+// Compile-time timing ablations (-DW2_ABL=bits; results are WRONG, never ship):
+//   1 no raw-tile DMA   2 weights loaded once   4 no LDS reads   8 no epilogue   16 no input-transform VALU
+#ifndef W2_ABL
+#define W2_ABL 0
+#endif
+#ifdef W2_TIMING
+// s_memtime stamps of workgroups 8 and 9 (debug builds only; tools/w2_timing.py): [wg][item][slot][wave]
+__device__ unsigned long long g_w2_dbg[2 * 4 * 40 * 4];
+#endif
+constexpr int W2_THREADS = 256;
+constexpr int W2_TW = 32, W2_TH = 4;           // pixel tile
+// LDS image of a channel's halo tile: 6 rows (y0-1 .. y0+4) of 40 floats = image columns x0-4 .. x0+35, i.e. ten
+// 16-byte groups per row that are ALIGNED to the tile (x0 is a multiple of 32): a group is either entirely left of
+// the image (x0 = 0: hardware zero fill through the per-lane out-of-range offset) or starts inside it.  60 groups =
+// ONE 16-bytes-per-lane LDS-DMA instruction per channel.
+constexpr int W2_RS = 40, W2_HR = W2_TH + 2;
+constexpr int W2_GRP = W2_RS / 4;              // 16-byte groups per row
+constexpr int W2_PLANE = W2_HR * W2_RS;        // 240 floats
+constexpr int W2_PS = 256;                     // plane stride (lanes 60..63 of the DMA write zeros into the pad)
+constexpr int W2_BUF = 16 * W2_PS;             // floats per raw-tile buffer (16-channel chunk)
+constexpr int W2_XCH = 4 * 32 * 32 * 2;        // exchange area: [i][32 channels][32 tiles][q]
+constexpr int W2_LDS_FLOATS = 2 * W2_BUF + W2_XCH;
+
+struct Wino2Item {          // one unit of work: a 4x32 pixel tile x one block of MT*16 output channels
+    int b, y0, x0, cb;
+};
+
+template <int MT, int ACT>
+__global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
+    constexpr int NT = 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem + 2 * W2_BUF;
+
+    // persistent workgroups: XCD `xcd` owns a contiguous range of tiles (its L2 serves their halos); workgroup `ls` of
+    // that XCD takes tiles ls, ls + wg_per_xcd, ... and runs ALL output-channel blocks of a tile back to back: the raw
+    // tile of the second block comes out of L2 (a few hundred cycles instead of an HBM round trip).  That matters
+    // more than it looks: memory operations complete in order, so every weight load a wave issues after a raw-tile
+    // DMA is held up until that DMA has landed.
+    const int xcd = blockIdx.x & 7;
+    const int ls = blockIdx.x >> 3;
+    const int tpi = p.tilesX * p.tilesY;
+    // (launches with fewer tiles than workgroups -- the coarse pyramid scales -- spread the channel blocks over
+    // workgroups instead: items ls, ls + wg_per_xcd, ... of the (tile, block) list)
+    const bool by_tile = p.tiles_per_xcd >= wg_per_xcd;
+    auto decode = [&](int k, Wino2Item& it) -> bool {          // k-th work item of this workgroup
+        int tl, cb;
+        if (by_tile) {
+            tl = ls + (k / p.coblks) * wg_per_xcd;              // tile inside the XCD's range
+            cb = k % p.coblks;
+        } else {
+            const int li = ls + k * wg_per_xcd;
+            if (li >= items_per_xcd) return false;
+            tl = li / p.coblks;
+            cb = li % p.coblks;
+        }
+        if (tl >= p.tiles_per_xcd) return false;
+        const int tile = xcd * p.tiles_per_xcd + tl;
+        if (tile >= p.ntiles) return false;
+        it.cb = cb;
+        it.b = tile / tpi;
+        const int trm = tile - it.b * tpi;
+        const int ty = trm / p.tilesX;
+        it.y0 = ty * W2_TH;
+        it.x0 = (trm - ty * p.tilesX) * W2_TW;
+        return true;
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wi = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = Winograd frequency row i
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+
+    // B^T rows: frequency row i combines patch rows  0: d0 - d2   1: d1 + d2   2: d1 - d2 (*)   3: d1 - d3
+    // (*) B^T row 2 is -d1 + d2; the sign lives in the packed weights (U_2j is stored negated), so every wave
+    //     evaluates  ra + sgn * rb  with sgn = +1 for i = 1 and -1 otherwise.
+    const int pa0 = wi == 0 ? 0 : 1, pa1 = wi == 3 ? 3 : 2;
+    const float sgn = wi == 1 ? 1.f : -1.f;
+    // patch columns of tile column tc: image x0+2tc-1 .. x0+2tc+2 = row positions 2tc+3 .. 2tc+6
+    const int oa = kq * W2_PS + pa0 * W2_RS + 2 * l16 + 3;        // + nt * 2 * RS + ks * 4 * PS
+    const int ob = kq * W2_PS + pa1 * W2_RS + 2 * l16 + 3;
+
+    const int nch = p.nch3;                                        // 16-channel chunks of the reduction
+    const int nks_total = nch * 4;
+
+    // ---- raw-tile DMA: wave w stages channels 4w..4w+3 of a chunk, one 16-bytes-per-lane instruction per channel ----
+    constexpr unsigned OOB = 0x40000000u;
+    unsigned goff;                                  // this lane's 16-byte group of the halo tile (per item)
+    bool cm[4];                                     // patch column c of this lane's tile column lies inside the image
+    auto make_goff = [&](const Wino2Item& it) {
+        const int row = lane / W2_GRP, grp = lane - row * W2_GRP;
+        const int gy = it.y0 + row - 1, gx = it.x0 - 4 + 4 * grp;
+        const bool ok = lane < W2_HR * W2_GRP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+        // a group that starts inside the image may run past its right edge (into the next row): those columns are
+        // replaced by the zero padding when the patch is read
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cm[c] = it.x0 + 2 * l16 - 1 + c < W;
+    };
+    // `valid` = false issues the same instructions with empty descriptors (zero fill): the instruction stream of a
+    // chunk is the same for every chunk, so the compiler's vmcnt bookkeeping is exact (no control-flow merge)
+    auto issue1 = [&](int ib, int c, bool valid, float* buf, int g) {     // channel g (0..3) of this wave; ib = sample
+        const int kc = wi * 4 + g;
+        const int ch = c * 16 + kc;
+        const bool live = valid && ch < p.Cin;
+        const float* sbase = p.in + ((size_t)ib * p.Cin + (live ? ch : 0)) * HW;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sbase), 0, live ? HW * 4 : 0, 0x00020000);
+        float* pl = buf + kc * W2_PS;
+        if (W2_ABL & 1) return;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)pl, 16, (int)goff, 0, 0, 0);
+    };
+    auto issue = [&](int ib, int c, bool valid, float* buf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) issue1(ib, c, valid, buf, g);
+    };
+
+    // ---- weights: register image [coblk][chunk][i][ks][mt][lane][j], 16-byte buffer loads ----
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFF0, 0x00020000);
+    const int wlane = lane * 16;
+    f32x4 a[MT];                                                   // A operands of the current k-step
+    // g = k-step index inside the item; g == nks_total means "k-step 0 of the next item" (output-channel block ncb):
+    // the weight stream, like the raw-tile stream, runs across items without a branch inside a k-step -- a chunk stays
+    // one basic block, which the register allocator needs to accumulate in place
+    auto load_w = [&](int mt, int cb, int ncb, int g) {
+        if ((W2_ABL & 2) && g > 0) return;
+        const bool wrap = g >= nks_total;
+        const int gg = wrap ? 0 : g;
+        const int so = (((wrap ? ncb : cb) * nch + (gg >> 2)) * 4 + wi) * (4096 * MT) + (gg & 3) * (1024 * MT) + mt * 1024;
+        a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
+    };
+    // Barriers are written in assembly: hipcc puts a full `s_waitcnt vmcnt(0)` in front of every s_barrier on gfx9,
+    // which would drain the weight loads issued a moment ago (main loop) and expose the completion latency of every
+    // global store (epilogue).
+    //   chunk barrier: what it needs is (a) this wave's raw-tile DMA of the next chunk landed -- it is OLDER than the MT
+    //   weight loads of the k-step before the barrier and memory operations complete in order, so vmcnt(MT) covers it;
+    //   (b) this wave's LDS reads of the current chunk done: lgkmcnt(0).
+    auto chunk_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT) : "memory");
+    };
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // B operands of one k-step: V[nt][j] from the two patch rows of this wave's frequency row
+    auto read_raw = [&](const float* base, f32x4 (&ra)[NT], f32x4 (&rb)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (W2_ABL & 4) { ra[nt] = f32x4{1.f, 2.f, 3.f, 4.f}; rb[nt] = f32x4{(float)lane, 1.f, 0.f, 2.f}; continue; }
+            const float* qa = base + oa + nt * 2 * W2_RS;
+            const float* qb = base + ob + nt * 2 * W2_RS;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ra[nt][c] = qa[c];
+                rb[nt][c] = qb[c];
+            }
+        }
+    };
+    auto transform = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (W2_ABL & 4) { v[nt][0] = ra[nt][0]; v[nt][1] = rb[nt][0]; v[nt][2] = ra[nt][2]; v[nt][3] = rb[nt][1]; continue; }
+            // columns right of the image edge hold the next row's pixels (the 16-byte groups run past it): zero padding
+            float r0 = fmaf(sgn, rb[nt][0], ra[nt][0]), r1 = fmaf(sgn, rb[nt][1], ra[nt][1]);
+            float r2 = fmaf(sgn, rb[nt][2], ra[nt][2]), r3 = fmaf(sgn, rb[nt][3], ra[nt][3]);
+            r0 = cm[0] ? r0 : 0.f; r1 = cm[1] ? r1 : 0.f; r2 = cm[2] ? r2 : 0.f; r3 = cm[3] ? r3 : 0.f;
+            v[nt][0] = r0 - r2;      // B columns: 0: c0 - c2   1: c1 + c2   2: c2 - c1   3: c1 - c3
+            v[nt][1] = r1 + r2;
+            v[nt][2] = r2 - r1;
+            v[nt][3] = r1 - r3;
+        }
+    };
+
+    // The same two steps cut into 8 pieces each, one per MFMA of an m-tile group (fine-grained schedule below)
+    auto read_piece = [&](const float* base, f32x4 (&ra)[NT], f32x4 (&rb)[NT], int q) {
+        const int row = q & 1, nt = (q >> 1) & 1, half = q >> 2;
+        if (W2_ABL & 4) { (row ? rb : ra)[nt][half * 2] = (float)q; (row ? rb : ra)[nt][half * 2 + 1] = (float)lane; return; }
+        const float* src = base + (row ? ob : oa) + nt * 2 * W2_RS + half * 2;
+        (row ? rb : ra)[nt][half * 2] = src[0];
+        (row ? rb : ra)[nt][half * 2 + 1] = src[1];
+    };
+    float tr_[4];                                   // row-combined patch of the tile-row being transformed
+    auto transform_piece = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4], int q) {
+        const int nt = q >> 2;
+        if (W2_ABL & 16) { if ((q & 3) == 0) { v[nt][0] = ra[nt][0]; v[nt][1] = rb[nt][1]; v[nt][2] = ra[nt][2]; v[nt][3] = rb[nt][3]; } return; }
+        switch (q & 3) {
+            case 0:
+                tr_[0] = fmaf(sgn, rb[nt][0], ra[nt][0]);
+                tr_[1] = fmaf(sgn, rb[nt][1], ra[nt][1]);
+                tr_[2] = fmaf(sgn, rb[nt][2], ra[nt][2]);
+                break;
+            case 1:
+                tr_[3] = fmaf(sgn, rb[nt][3], ra[nt][3]);
+                tr_[0] = cm[0] ? tr_[0] : 0.f;
+                tr_[1] = cm[1] ? tr_[1] : 0.f;
+                break;
+            case 2:
+                tr_[2] = cm[2] ? tr_[2] : 0.f;
+                tr_[3] = cm[3] ? tr_[3] : 0.f;
+                v[nt][0] = tr_[0] - tr_[2];
+                break;
+            default:
+                v[nt][1] = tr_[1] + tr_[2];
+                v[nt][2] = tr_[2] - tr_[1];
+                v[nt][3] = tr_[1] - tr_[3];
+        }
+    };
+
+    Wino2Item it;
+    int l = 0;
+    if (!decode(l, it)) return;
+#if W2_DESYNC
+    {
+        // The two workgroups of a CU start together and their items take equal time, so left alone they stay in phase
+        // (both in the epilogue at once = the matrix pipe idles exactly as in the 16-wave kernel).  The hardware wave slot
+        // (HW_REG_HW_ID[3:0]) tells the first-dispatched workgroup of a SIMD from the second.
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+        if (W2_DESYNC & 1) {
+            // static priority: the slot-1 workgroup owns the matrix pipe whenever it has MFMAs to issue; the other one
+            // fills every gap it leaves (its epilogues, barrier ramps, prologues) and gets the pipe alone meanwhile
+            if (slot) __builtin_amdgcn_s_setprio(1);
+        }
+        if (W2_DESYNC & 2) {
+            // start the slot-1 workgroup about half a work item late
+            if (slot) {
+                for (int i = 0; i < nch; ++i) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+    }
+#endif
+    make_goff(it);
+    issue(it.b, 0, true, smem);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) load_w(mt, it.cb, it.cb, 0);
+    __syncthreads();
+    int nb = 0;                                    // raw buffer holding the current chunk (runs across items)
+    float v[2][NT][4];                             // B operands, double buffered by k-step parity (runs across items)
+    {
+        f32x4 ra[NT], rb[NT];
+        read_raw(smem, ra, rb);
+        transform(ra, rb, v[0]);
+    }
+#ifdef W2_TIMING
+    int dbg_item = 0;
+    const int dbg_wg = blockIdx.x == 8 ? 0 : 1;
+#endif
+
+    for (;;) {
+        Wino2Item nx;
+        l += 1;
+        const bool have_next = decode(l, nx);
+        if (!have_next) nx = it;
+#ifdef W2_TIMING
+        const bool dbg = (blockIdx.x == 8 || blockIdx.x == 8 + 8 * 32) && dbg_item < 4 && lane == 0;
+        if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 39) * 4 + wi] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+#endif
+        f32x4 acc[MT][NT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][nt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // Schedule of a 16-channel chunk (4 k-steps of 8*MT MFMAs):
+        //   k-step 0   : LDS-DMA of the NEXT chunk of this workgroup's stream (chunk c+1, or chunk 0 of the next item)
+        //                into the other raw buffer
+        //   k-step ks  : per m-tile 8 MFMAs, then the refill of that m-tile's A registers with k-step ks+1; the raw
+        //                patches of k-step ks+1 are read from LDS beside the MFMAs of the first m-tile and transformed
+        //                into B operands beside those of the third
+        //   barrier    : BEFORE the last k-step, not after it: every read of the current raw buffer has been issued by
+        //                then (k-step 3's operands are in registers), the next chunk's DMA landed long ago, and each wave
+        //                leaves the barrier with 8*MT MFMAs ready whose shadow hides the first LDS round trip of the next
+        //                chunk.  (A barrier at the end of the chunk exposes that round trip: 10 % of a chunk.)
+        for (int c = 0; c < nch; ++c) {
+            const float* cur = smem + nb * W2_BUF;
+            float* nxt = smem + (nb ^ 1) * W2_BUF;
+            const bool last = c + 1 == nch;
+#ifdef W2_TIMING
+            if (dbg && c < 12) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 3 * c + 0) * 4 + wi] = __builtin_amdgcn_s_memtime();
+#endif
+            if (last) make_goff(nx);
+            const int dsrc = last ? nx.b : it.b;
+            const int dch = last ? 0 : c + 1;
+            const bool dval = !last || have_next;
+            if (MT < 3) issue(dsrc, dch, dval, nxt);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int g = c * 4 + ks;
+                if (ks == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef W2_TIMING
+                    if (dbg && c < 12) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 3 * c + 1) * 4 + wi] = __builtin_amdgcn_s_memtime();
+#endif
+                    chunk_barrier();
+#ifdef W2_TIMING
+                    if (dbg && c < 12) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 3 * c + 2) * 4 + wi] = __builtin_amdgcn_s_memtime();
+#endif
+                }
+                const float* rsrc_ = ks < 3 ? cur + (ks + 1) * 4 * W2_PS : nxt;
+                f32x4 ra[NT], rb[NT];
+                if constexpr (MT >= 3) {
+                    // Fine-grained, pinned order (a sched_barrier after every piece): one MFMA occupies the matrix pipe
+                    // for 32 cycles, and whatever this wave issues in that shadow is free -- whatever it issues in a
+                    // block in FRONT of its MFMAs is a bubble nobody fills when the wave is alone on its SIMD.
+                    //   m-tile 0: after each of its 8 MFMAs one LDS read (2 floats) of the next k-step's raw patches
+                    //   m-tile 2: after each of its 8 MFMAs three VALU of the next k-step's input transform
+                    //   every m-tile: after its MFMAs the refill of its A registers; in k-step 0 also one channel of the
+                    //   next chunk's LDS-DMA (m-tiles 1..4: its ~25 SALU of descriptor arithmetic ride along)
+#ifdef W2_KT_KS
+                    unsigned long long kt[MT + 1];
+                    if (ks == W2_KT_KS) kt[0] = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
+                                                                                          acc[mt][q >> 2][q & 3], 0, 0, 0);
+                            if (mt == 0) read_piece(rsrc_, ra, rb, q);
+                            if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q);
+                            if (mt == 0 || mt == 2) __builtin_amdgcn_sched_barrier(0);
+                        }
+                        load_w(mt, it.cb, nx.cb, g + 1);
+                        // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
+                        // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Spread out on purpose: a wave
+                        // BLOCKS at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy --
+                        // four of them issued back to back cost ~2000 cycles without a single MFMA.
+                        if (ks == 0 && mt >= 1) issue1(dsrc, dch, dval, nxt, mt - 1);
+                        if (ks == 0 && mt == MT - 1) {
+#pragma unroll
+                            for (int gch = MT - 1; gch < 4; ++gch) issue1(dsrc, dch, dval, nxt, gch);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#ifdef W2_KT_KS
+                        if (ks == W2_KT_KS) { kt[mt + 1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+                    }
+#ifdef W2_KT_KS
+                    if (ks == W2_KT_KS && dbg && c == 2) {
+#pragma unroll
+                        for (int i = 0; i <= MT; ++i) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 20 + i) * 4 + wi] = kt[i];
+                    }
+#endif
+                } else {
+                    read_raw(rsrc_, ra, rb);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (mt == MT - 1) transform(ra, rb, v[(ks + 1) & 1]);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
+                                                                                          acc[mt][q >> 2][q & 3], 0, 0, 0);
+                        load_w(mt, it.cb, nx.cb, g + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            nb ^= 1;
+        }
+
+        // ---- output transform + epilogue: column half in registers, row half through LDS, 32 channels per pass ----
+#ifdef W2_TIMING
+        if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 36) * 4 + wi] = __builtin_amdgcn_s_memtime();
+#endif
+        if (W2_ABL & 8) {
+            float sink = 0.f;                                   // keep every accumulator chain alive
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sink += acc[mt][nt][j][0] + acc[mt][nt][j][1] + acc[mt][nt][j][2] + acc[mt][nt][j][3];
+            if (sink == 123.456f) p.out[tid] = sink;
+            if (!have_next) break;
+            it = nx;
+            continue;
+        }
+        const int tile = tid & 31;                     // reader role: 2x2 tile (tile-row, tile-col) ...
+        const int tr = tile >> 4, tc = tile & 15;
+        const int cg = tid >> 5;                       // ... and channels cg + 8k of a pass
+        const int y = it.y0 + 2 * tr, x = it.x0 + 2 * tc;
+        const bool x1ok = x + 1 < W;
+        // Every global access of the epilogue is a BUFFER access on a per-sample descriptor (one sample's Cout planes:
+        // < 4 GB even at 411x512): lanes without a pixel / channel carry an out-of-range offset, which the hardware
+        // drops (stores) or zero-fills (loads) -- no exec-masked branches, so all loads of a pass are in flight together.
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        const unsigned plane_b = (unsigned)HW * 4u;
+        const unsigned samp_b = (unsigned)p.Cout * plane_b;
+        const size_t samp_o = (size_t)it.b * p.Cout * HW;
+        auto rsrc_of = [&](const float* base) {
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base ? base + samp_o : p.zero), 0,
+                                                     base ? samp_b : 0u, 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rs_out = rsrc_of(p.out), rs_res = rsrc_of(p.resid);
+        const __amdgpu_buffer_rsrc_t rs_aux = rsrc_of(ACT == 2 ? p.aux : nullptr);
+        const __amdgpu_buffer_rsrc_t rs_pre = rsrc_of(ACT == 1 ? p.out_pre : nullptr);
+        const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
+        const bool pix_ok = y < H && x < W;
+        const bool row1 = y + 1 < H;
+        const unsigned pix_o = ((unsigned)(it.cb * (MT * 16) + cg) * (unsigned)HW + (unsigned)(y * W + x)) * 4u;
+        // byte offset of (channel k of pass m0, row pp) or OOB
+        auto off_of = [&](int m0, int k, int pp) -> unsigned {
+            const int cl = cg + 8 * k;
+            const bool ok = pix_ok && (pp == 0 || row1) && (m0 * 16 + cl < MT * 16) &&
+                            (it.cb * (MT * 16) + m0 * 16 + cl < p.Cout);
+            return ok ? pix_o + (unsigned)(m0 * 16 + 8 * k) * plane_b + (unsigned)(pp * W) * 4u : OOB;
+        };
+        auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o) -> f32x2 {
+            return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)o, 0, 0));
+        };
+        // an 8-byte store covers pixels (x, x+1); in the last odd column only pixel x exists: 4-byte store instead
+        const bool edge_tile = it.x0 + W2_TW > W;                   // (wave-uniform) the tile reaches the right image edge
+        auto st2 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o, f32x2 vv) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, vv), r, (int)(x1ok ? o : OOB), 0, 0);
+            if (edge_tile)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[0]), r, (int)(x1ok ? OOB : o), 0, 0);
+        };
+        // residual / pre-activation / bias operands of a pass: requested one pass AHEAD, before the stores of the pass in
+        // between -- memory operations complete in order, so a wait for them never waits for a store
+        f32x2 rs_v[4][2], ax_v[4][2];
+        float bs_v[4];
+        auto prefetch = [&](int m0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bs_v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_bias, (it.cb * (MT * 16) + m0 * 16 + cg + 8 * k) * 4, 0, 0));
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const unsigned o = off_of(m0, k, pp);
+                    rs_v[k][pp] = ld2(rs_res, o);
+                    if (ACT == 2) ax_v[k][pp] = ld2(rs_aux, o);
+                }
+            }
+        };
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (m0 + h < MT) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            // (M A)[i][q]:  q = 0: m0 + m1 + m2,  q = 1: m1 - m2 - m3
+                            const float m_0 = acc[m0 + h][nt][0][r], m_1 = acc[m0 + h][nt][1][r];
+                            const float m_2 = acc[m0 + h][nt][2][r], m_3 = acc[m0 + h][nt][3][r];
+                            f32x2 t{m_0 + m_1 + m_2, m_1 - m_2 - m_3};
+                            *reinterpret_cast<f32x2*>(sX + (((wi * 32 + h * 16 + kq * 4 + r) * 32) + nt * 16 + l16) * 2) = t;
+                        }
+                }
+            }
+            if (m0 == 0) prefetch(0);                              // (its accumulators are dead: registers are free)
+            lds_barrier();
+            f32x2 yv[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cl = cg + 8 * k;                         // channel of the pass (0..31)
+                f32x2 t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f32x2*>(sX + ((i * 32 + cl) * 32 + tile) * 2);
+                yv[k][0] = t[0] + t[1] + t[2];                     // Y[pp][q] = sum_i A^T[pp][i] t[i][q]
+                yv[k][1] = t[1] - t[2] - t[3];
+            }
+            lds_barrier();                                         // the exchange area is free for the next pass
+            f32x2 val[4][2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    f32x2 w_ = yv[k][pp] + bs_v[k];
+                    if (ACT == 1) {
+                        yv[k][pp] = w_;                            // pre-activation (training forward saves it)
+                        w_[0] = gelu_erf(w_[0]);
+                        w_[1] = gelu_erf(w_[1]);
+                    } else if (ACT == 2) {
+                        w_[0] *= gelu_erf_grad(ax_v[k][pp][0]);
+                        w_[1] *= gelu_erf_grad(ax_v[k][pp][1]);
+                    }
+                    val[k][pp] = w_ + rs_v[k][pp];
+                }
+            }
+            if (m0 + 2 < MT) prefetch(m0 + 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    const unsigned o = off_of(m0, k, pp);
+                    if (ACT == 1) st2(rs_pre, o, yv[k][pp]);       // (empty descriptor when out_pre is null: dropped)
+                    st2(rs_out, o, val[k][pp]);
+                }
+            }
+        }
+#ifdef W2_TIMING
+        if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 37) * 4 + wi] = __builtin_amdgcn_s_memtime();
+        ++dbg_item;
+#endif
+        if (!have_next) break;
+        it = nx;                                   // goff / cm already describe nx
+    }
+}
+
+template <int MT>
+inline void conv_wino2_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
+#ifdef W2_ONE_WG
+    constexpr size_t lds = 100 * 1024;                       // (experiment) only one workgroup fits a CU
+#else
+    constexpr size_t lds = W2_LDS_FLOATS * sizeof(float);
+#endif
+    switch (a.act & 0xff) {
+        case 1: hipLaunchKernelGGL((conv_wino2_kernel<MT, 1>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
+        case 2: hipLaunchKernelGGL((conv_wino2_kernel<MT, 2>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
+        default: hipLaunchKernelGGL((conv_wino2_kernel<MT, 0>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx);
+    }
+}
+
+inline int wino2_cu_count() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    return n;
+}
+
+inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
+    ConvArgs a = a_in;
+    ConvProfiler& prof = conv_profiler();
+    const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
+    if (rec) {
+        while (prof.created <= prof.used) {
+            (void)hipEventCreate(&prof.ev[2 * prof.created]);
+            (void)hipEventCreate(&prof.ev[2 * prof.created + 1]);
+            ++prof.created;
+        }
+        (void)hipEventRecord(prof.ev[2 * prof.used], st);
+    }
+    a.tilesX = (a.W + W2_TW - 1) / W2_TW;
+    a.tilesY = (a.H + W2_TH - 1) / W2_TH;
+    a.ntiles = a.B * a.tilesX * a.tilesY;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    // persistent launch: two 4-wave workgroups per CU, each walking its share of the XCD's work items
+    const int ipx = a.tiles_per_xcd * a.coblks;                  // work items per XCD
+#ifdef W2_ONE_WG
+    int wpx = wino2_cu_count() / 8;
+#else
+    int wpx = wino2_cu_count() / 8 * 2;                          // workgroups per XCD
+#endif
+    if (wpx < 1) wpx = 1;
+    if (wpx > ipx) wpx = ipx;
+    const unsigned grid = (unsigned)(wpx * 8);
+    switch (mt) {
+        case 5: conv_wino2_launch_t<5>(a, grid, ipx, wpx, st); break;
+        case 2: conv_wino2_launch_t<2>(a, grid, ipx, wpx, st); break;
+        case 1: conv_wino2_launch_t<1>(a, grid, ipx, wpx, st); break;
+        default: return SINDDM_E_BADSHAPE;
+    }
+    if (rec) {
+        (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
+        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        prof.note(1, fl, fl * (16.0 / 36.0));
+    }
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sinddm

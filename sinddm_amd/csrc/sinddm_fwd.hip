@@ -45,6 +45,19 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
     } else if (g.kind == 3) {
         // Winograd F(2x2,3x3): U_xi = G g G^T in the MFMA A-operand register image
         // [coblk][chunk of 16 ci][xi][ks][mt][lane]; lane -> (co = lane&15, ci = lane>>4)
+#if SINDDM_WINO_V2
+        // second-generation kernel (conv_wino2.h): [coblk][chunk][i][ks][mt][lane][j] -- a lane's four frequencies
+        // (i, 0..3) are one 16-byte load; frequency row 2 is stored negated (the kernel evaluates d1 - d2 for it)
+        long long r = j;
+        const int fj_ = (int)(r % 4); r /= 4;
+        const int lane = (int)(r % 64); r /= 64;
+        const int mt = (int)(r % g.mt); r /= g.mt;
+        const int ks = (int)(r % 4); r /= 4;
+        const int fi_ = (int)(r % 4); r /= 4;
+        const int xi = fi_ * 4 + fj_;
+        const int ch = (int)(r % g.nch); r /= g.nch;
+        const int cb = (int)r;
+#else
         const int lane = (int)(j % 64);
         long long r = j / 64;
         const int mt = (int)(r % g.mt); r /= g.mt;
@@ -52,6 +65,7 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
         const int xi = (int)(r % 16); r /= 16;
         const int ch = (int)(r % g.nch); r /= g.nch;
         const int cb = (int)r;
+#endif
         const int m = cb * g.mt * 16 + mt * 16 + (lane & 15);
         const int k = ch * 16 + ks * 4 + (lane >> 4);
         const int M = g.transpose ? g.cin : g.cout;      // rows of THIS conv
@@ -76,7 +90,7 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
                 for (int b2 = 0; b2 < 3; ++b2) rowv += G[fj][b2] * gt[a][b2];
                 acc += G[fi][a] * rowv;
             }
-            v = acc;
+            v = (SINDDM_WINO_V2 && fi == 2) ? -acc : acc;
         }
     } else if (g.kind == 1) {
         if (j < g.cout) {
@@ -720,6 +734,11 @@ int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_
     return 0;
 }
 
+#ifdef W2_TIMING
+int sinddm_debug_w2_timing(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_dbg), sizeof(unsigned long long) * n);
+}
+#endif
 #ifdef SINDDM_WINO_TIMING
 int sinddm_debug_wino_timing(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wino_dbg), sizeof(unsigned long long) * n);

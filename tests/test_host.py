@@ -264,3 +264,19 @@ def test_bench_refuses_missing_gpus():
                        text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "exposes only" in (r.stderr + r.stdout)
+
+
+def test_save_image_single_image_is_not_padded(tmp_path):
+    """torchvision.utils.save_image writes a single (3,H,W) / (1,3,H,W) image as it is -- no grid frame
+    (reference trainer.py:283-285 writes the final unbatched samples this way); batches get the 2-px grid."""
+    from PIL import Image
+    from sinddm_amd.trainer import save_image
+    img = torch.rand(3, 20, 30)
+    save_image(img, str(tmp_path / "a.png"))
+    save_image(img[None], str(tmp_path / "b.png"))
+    assert Image.open(tmp_path / "a.png").size == (30, 20)
+    assert Image.open(tmp_path / "b.png").size == (30, 20)
+    a = np.asarray(Image.open(tmp_path / "a.png"))
+    assert np.array_equal(a, (img.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy())
+    save_image(torch.rand(5, 3, 20, 30), str(tmp_path / "c.png"), nrow=4)
+    assert Image.open(tmp_path / "c.png").size == (4 * 32 + 2, 2 * 22 + 2)
