@@ -103,6 +103,22 @@ int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde
                         const float* noise, float* out, const sinddm_step_coefs* coefs /*host*/,
                         int64_t n, void* stream);
 
+/* A run of reverse steps of one scale WITHOUT returning to the host between them: for i in [0, n_steps):
+ *   eps = SinDDMNet(x_i, t_list[i], scale);  x_{i+1} = p_sample tail(x_i, eps, x_tilde, z_i; coefs[i])
+ * = the body of p_sample_loop / p_sample_via_scale_loop (reference SinDDM/models.py:462-487,501-547).  The N(0,1)
+ * draws z_i of models.py:455 are generated INSIDE the step kernel (Philox4x32-10 + Box-Muller; stream = (seed,
+ * stream_id0 + i, element index)) -- the reference never seeds its generator, so only the distribution is contract;
+ * callers that must inject recorded noise use sinddm_net_forward + sinddm_reverse_step per step instead.
+ *   x       (B,3,H,W) state in; x_alt same-size scratch: the states ping-pong, *result_in_alt tells where x_n is
+ *   eps     (B,3,H,W) scratch;  coefs / t_list: HOST arrays of n_steps entries;  ws as for sinddm_net_forward  */
+int sinddm_sample_chain(const float* params, const float* packed, float* x, float* x_alt, float* eps,
+                        const float* x_tilde, const sinddm_step_coefs* coefs /*host*/, const int* t_list /*host*/,
+                        int n_steps, float scale, uint64_t seed, uint64_t stream_id0, int dim, int B, int H, int W,
+                        void* ws, size_t ws_bytes, void* stream, int* result_in_alt /*host*/);
+
+/* out[i] ~ N(0,1) from the same counter-based generator (the sampler's initial / re-noise draws, models.py:467,518) */
+int sinddm_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
 /* Same step with the reference's ROI guidance folded in (roi_patch_modification, models.py:291-298, applied at
  * :430-431 when roi_guided_sampling and s < n_scales-1): the predicted clean image x_recon becomes
  * edit_w[p] * x_recon + edit_c[ch][p] before the re-blur mix and the clamps.  edit_w: HW floats, edit_c: C*HW

@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2", "sinddm_prof_end3",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
-    "sinddm_cond_embed", "sinddm_cond_stride",
+    "sinddm_cond_embed", "sinddm_cond_stride", "sinddm_sample_chain", "sinddm_normal_fill",
 )
 
 
@@ -67,6 +67,9 @@ def load() -> C.CDLL:
         "sinddm_q_sample": (i, [p, p, p, p, p, p, p, p, i, i, i64, p]),
         "sinddm_reverse_step": (i, [p, p, p, p, p, C.POINTER(StepCoefs), i64, p]),
         "sinddm_reverse_step_edit": (i, [p, p, p, p, p, C.POINTER(StepCoefs), p, p, i, i, i, p]),
+        "sinddm_sample_chain": (i, [p, p, p, p, p, p, C.POINTER(StepCoefs), C.POINTER(C.c_int), i, f, C.c_uint64, C.c_uint64,
+                                    i, i, i, i, p, sz, p, C.POINTER(C.c_int)]),
+        "sinddm_normal_fill": (i, [p, i64, C.c_uint64, C.c_uint64, p]),
         "sinddm_upsample_bilinear": (i, [p, p, i, i, i, i, i, p]),
         "sinddm_prof_begin": (i, []),
         "sinddm_prof_end": (i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

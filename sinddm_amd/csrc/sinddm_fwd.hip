@@ -446,6 +446,33 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
 // EDIT: the predicted clean image is replaced by  w(p) * x_recon + c(ch, p)  before the re-blur mix / clamps --
 // the ROI-guided sampling of the reference (models.py:291-298,430-431) written as a per-pixel affine map
 // (sequential `eta*patch + (1-eta)*x` blends over possibly overlapping boxes compose into one such map).
+// x_{t-1} mean of one element: predict_start_from_noise + p_mean_variance (normal branch) + q_posterior
+// (reference SinDDM/models.py:306-352,433-447); `w`, `c` = ROI edit map (1, 0 without ROI guidance)
+__device__ __forceinline__ float reverse_step_mean(const sinddm_step_coefs& k, float x, float e, float xb, float w, float c,
+                                                   bool edit) {
+    float x0 = k.sqrt_recip_ac_t * x - k.sqrt_recipm1_ac_t * e;                   // models.py:308-309
+    if (k.mode == 0) {
+        if (edit) x0 = w * x0 + c;              // x_recon and x_t_mix are the same tensor here (models.py:311-312)
+        const float x0c = k.clip ? fminf(fmaxf(x0, -1.0f), 1.0f) : x0;
+        return k.coef1_t * x0c + k.coef2_t * x;                                   // models.py:324-327
+    }
+    float xp = (x0 - k.gamma_t * xb) / (1.0f - k.gamma_t);                        // models.py:315-316
+    if (edit) xp = w * xp + c;
+    if (k.mode == 1) {
+        float mix = k.gamma_tm1 * xb + (1.0f - k.gamma_tm1) * xp;                 // models.py:435-436
+        float x0c = x0;
+        if (k.clip) {
+            mix = fminf(fmaxf(mix, -1.0f), 1.0f);
+            x0c = fminf(fmaxf(x0, -1.0f), 1.0f);
+        }
+        return k.sqrt_ac_tm1 * mix + k.sqrt_1m_ac_tm1_mvar * (x - k.sqrt_ac_t * x0c) / k.sqrt_1m_ac_t;  // :342-345
+    }
+    return k.clip ? fminf(fmaxf(xp, -1.0f), 1.0f) : xp;                           // models.py:347-348
+}
+
+// EDIT: the predicted clean image is replaced by  w(p) * x_recon + c(ch, p)  before the re-blur mix / clamps --
+// the ROI-guided sampling of the reference (models.py:291-298,430-431) written as a per-pixel affine map
+// (sequential `eta*patch + (1-eta)*x` blends over possibly overlapping boxes compose into one such map).
 template <bool EDIT>
 __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restrict__ xt, const float* __restrict__ eps,
                                                            const float* __restrict__ xtil, const float* __restrict__ z,
@@ -453,36 +480,79 @@ __global__ __launch_bounds__(256) void reverse_step_kernel(const float* __restri
                                                            const float* __restrict__ ew, const float* __restrict__ ec,
                                                            int chw, int hw) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float x = xt[i];
-        float x0 = k.sqrt_recip_ac_t * x - k.sqrt_recipm1_ac_t * eps[i];         // models.py:308-309
         float w = 1.0f, c = 0.0f;
         if (EDIT) {
             const int q = (int)(i % chw);
             w = ew[q % hw];
             c = ec[q];
         }
-        float mean;
-        if (k.mode == 0) {
-            if (EDIT) x0 = w * x0 + c;          // x_recon and x_t_mix are the same tensor here (models.py:311-312)
-            const float x0c = k.clip ? fminf(fmaxf(x0, -1.0f), 1.0f) : x0;
-            mean = k.coef1_t * x0c + k.coef2_t * x;                               // models.py:324-327
-        } else {
-            const float xb = xtil[i];
-            float xp = (x0 - k.gamma_t * xb) / (1.0f - k.gamma_t);                // models.py:315-316
-            if (EDIT) xp = w * xp + c;
-            if (k.mode == 1) {
-                float mix = k.gamma_tm1 * xb + (1.0f - k.gamma_tm1) * xp;         // models.py:435-436
-                float x0c = x0;
-                if (k.clip) {
-                    mix = fminf(fmaxf(mix, -1.0f), 1.0f);
-                    x0c = fminf(fmaxf(x0, -1.0f), 1.0f);
-                }
-                mean = k.sqrt_ac_tm1 * mix + k.sqrt_1m_ac_tm1_mvar * (x - k.sqrt_ac_t * x0c) / k.sqrt_1m_ac_t;  // :342-345
-            } else {
-                mean = k.clip ? fminf(fmaxf(xp, -1.0f), 1.0f) : xp;               // models.py:347-348
-            }
-        }
+        const float mean = reverse_step_mean(k, xt[i], eps[i], k.mode != 0 ? xtil[i] : 0.0f, w, c, EDIT);
         out[i] = mean + k.sigma * z[i];                                           // models.py:459
+    }
+}
+
+// ---- the same step with the Gaussian noise of models.py:455 drawn INSIDE the kernel (counter-based Philox4x32-10 +
+// Box-Muller): no randn launch, no noise tensor (12 B/px less traffic).  Stream = (seed, step id, element index); the
+// reference never seeds its generator, so there is no bit-level noise contract -- parity tests keep injecting noise
+// through sinddm_reverse_step.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned long long step, unsigned long long idx4,
+                                               float (&z)[4]) {
+    unsigned c[4] = {(unsigned)idx4, (unsigned)(idx4 >> 32), (unsigned)step, (unsigned)(step >> 32)};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    // uniforms in (0, 1]: (x + 1) * 2^-32 evaluated so that 0 is never produced
+    const float u0 = ((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u1 = (float)(c[1] >> 8) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 1.0f) * (1.0f / 16777216.0f), u3 = (float)(c[3] >> 8) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincospif(2.0f * u1, &s0, &c0);
+    sincospif(2.0f * u3, &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
+__global__ __launch_bounds__(256) void reverse_step_rng_kernel(const float* __restrict__ xt, const float* __restrict__ eps,
+                                                               const float* __restrict__ xtil, float* __restrict__ out,
+                                                               sinddm_step_coefs k, long long n, unsigned long long seed,
+                                                               unsigned long long step) {
+    const long long n4 = (n + 3) >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k.sigma != 0.0f) philox_normal4(seed, step, (unsigned long long)q, z);
+        const long long i0 = q << 2;
+        if (i0 + 3 < n) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xt + i0);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(eps + i0);
+            f32x4 xb{0.f, 0.f, 0.f, 0.f};
+            if (k.mode != 0) xb = *reinterpret_cast<const f32x4*>(xtil + i0);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = reverse_step_mean(k, x[j], e[j], xb[j], 1.f, 0.f, false) + k.sigma * z[j];
+            *reinterpret_cast<f32x4*>(out + i0) = o;
+        } else {
+            for (int j = 0; i0 + j < n; ++j)
+                out[i0 + j] = reverse_step_mean(k, xt[i0 + j], eps[i0 + j], k.mode != 0 ? xtil[i0 + j] : 0.f, 1.f, 0.f, false) +
+                              k.sigma * z[j];
+        }
+    }
+}
+
+// standalone N(0,1) fill from the same generator (tests; initial / re-noise draws of the sampler)
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed,
+                                                            unsigned long long step) {
+    const long long n4 = (n + 3) >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        float z[4];
+        philox_normal4(seed, step, (unsigned long long)q, z);
+        for (int j = 0; j < 4 && (q << 2) + j < n; ++j) out[(q << 2) + j] = z[j];
     }
 }
 
@@ -715,6 +785,43 @@ int sinddm_reverse_step(const float* x_t, const float* eps, const float* x_tilde
     hipLaunchKernelGGL(reverse_step_kernel<false>, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x_t, eps, x_tilde, noise, out, *coefs, (long long)n, nullptr, nullptr, 1, 1);
     SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+    if (!out || n <= 0) return SINDDM_E_BADARG;
+    long long bx = ((n + 3) / 4 + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), out,
+                       (long long)n, (unsigned long long)seed, (unsigned long long)stream_id);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_sample_chain(const float* params, const float* packed, float* x, float* x_alt, float* eps, const float* x_tilde,
+                        const sinddm_step_coefs* coefs, const int* t_list, int n_steps, float scale, uint64_t seed,
+                        uint64_t stream_id0, int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream,
+                        int* result_in_alt) {
+    if (!params || !packed || !x || !x_alt || !eps || !coefs || !t_list || !ws || n_steps < 0 || B <= 0 || H <= 0 || W <= 0)
+        return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long n = (long long)B * CHANNELS * H * W;
+    long long bx = ((n + 3) / 4 + 255) / 256;
+    if (bx > 8192) bx = 8192;
+    float* cur = x;
+    float* nxt = x_alt;
+    for (int i = 0; i < n_steps; ++i) {
+        if (coefs[i].mode != 0 && !x_tilde) return SINDDM_E_BADARG;
+        int rc = net_forward_impl(p, params, packed, cur, nullptr, t_list[i], scale, eps, B, H, W, ws, ws_bytes, st, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL(reverse_step_rng_kernel, dim3((unsigned)bx), dim3(256), 0, st, cur, eps, x_tilde, nxt, coefs[i], n,
+                           (unsigned long long)seed, (unsigned long long)(stream_id0 + (uint64_t)i));
+        SINDDM_LAUNCH_CHECK();
+        float* t_ = cur; cur = nxt; nxt = t_;
+    }
+    if (result_in_alt) *result_in_alt = (cur == x_alt) ? 1 : 0;
     return 0;
 }
 

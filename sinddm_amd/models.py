@@ -519,6 +519,63 @@ class MultiScaleGaussianDiffusion(nn.Module):
         return self.q_posterior(x_start=x_tm1_mix, x_t_mix=x_t_mix, x_t=x, t=t, s=s)
 
     # ---- hot path -----------------------------------------------------------------------------
+    def _coef_table(self, s: int, clip_denoised: bool = True):
+        """`step_coefs` of every t of scale s as one ctypes array (built once per schedule / reblurring / omega)."""
+        key = (int(s), bool(clip_denoised), bool(self.reblurring), float(self.omega))
+        self._host()                                             # refreshes self._host_ver
+        cache = getattr(self, "_coef_cache", None)
+        if cache is None or cache.get("ver") != self._host_ver:
+            cache = {"ver": self._host_ver}
+            self._coef_cache = cache
+        tab = cache.get(key)
+        if tab is None:
+            tab = (_lib.StepCoefs * self.num_timesteps)(*[self.step_coefs(t, s, clip_denoised)
+                                                          for t in range(self.num_timesteps)])
+            cache[key] = tab
+        return tab
+
+    def _run_steps(self, img: torch.Tensor, s: int, t_seq) -> torch.Tensor:
+        """The reverse steps `t_seq` of scale s (the loop bodies of models.py:477-485,536-546).  Production path: ONE
+        library call for the whole run -- the per-step scalars come from a prebuilt table, the states ping-pong between
+        two buffers, the N(0,1) draws of models.py:455 are generated inside the step kernel (sinddm_sample_chain), and
+        Python is not entered between steps.  Injected noise (`noise_fn`, parity tests), ROI guidance, intermediate
+        dumps and foreign denoisers take the step-by-step path."""
+        t_seq = [int(t) for t in t_seq]
+        s = int(s)
+        fast = (self.noise_fn is None and isinstance(self.denoise_fn, SinDDMNet) and not self.save_interm
+                and not self.clip_guided_sampling and not (self.roi_guided_sampling and s < self.n_scales - 1)
+                and len(t_seq) > 0 and img.is_cuda)
+        if not fast:
+            for i in t_seq:
+                img = self._p_sample_host_t(img, i, s)
+                self._dump_interm(img, s, f'output_t-{i:03}_s-{s}.png')
+            return img
+        lib = _lib.load()
+        net = self.denoise_fn
+        x = img.contiguous().clone()
+        x_alt = torch.empty_like(x)
+        eps = torch.empty_like(x)
+        B, Cc, H, W = x.shape
+        tab = self._coef_table(s)
+        n = len(t_seq)
+        coefs = (_lib.StepCoefs * n)(*[tab[t] for t in t_seq])
+        tl = (C.c_int * n)(*t_seq)
+        xt = None
+        if coefs[0].mode != 0 or coefs[n - 1].mode != 0:
+            xt = self.img_prev_upsample
+            if xt is None:
+                raise _lib.SinddmError("img_prev_upsample is not set (call sample_via_scale / p_sample_via_scale_loop)")
+            xt = xt.contiguous()
+        packed = net.packed_weights()
+        ws = _workspace(x.device, lib.sinddm_workspace_bytes(net.dim, B, H, W))
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))      # from torch's (seedable) CPU generator
+        in_alt = C.c_int(0)
+        _lib.check(lib.sinddm_sample_chain(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
+                                           _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
+                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device), C.byref(in_alt)),
+                   "sinddm_sample_chain")
+        return x_alt if in_alt.value else x
+
     def _eps(self, x, t_dev, t_host, s):
         if isinstance(self.denoise_fn, SinDDMNet):
             return self.denoise_fn.infer(x, None if t_dev is None else t_dev, int(t_host), float(s))
@@ -571,10 +628,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
             t_min = self.num_timesteps_ideal[s + 1]
         else:
             t_min = 0
-        for i in reversed(range(t_min, self.num_timesteps)):
-            img = self._p_sample_host_t(img, i, s)
-            self._dump_interm(img, s, f'output_t-{i:03}_s-{s}.png')
-        return img
+        return self._run_steps(img, s, reversed(range(t_min, self.num_timesteps)))
 
     def _dump_interm(self, img, s, name):
         """save_interm=True (models.py:469-485,520-546): PNG grid of the running sample after every step (debug aid;
@@ -608,10 +662,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
             t_min = self.num_timesteps_ideal[s + 1]
         else:
             t_min = 0
-        for i in reversed(range(t_min, total_t)):
-            img = self._p_sample_host_t(img, i, s)
-            self._dump_interm(img, s, f'output_t-{i:03}_s-{s}.png')
-        return img
+        return self._run_steps(img, s, reversed(range(t_min, total_t)))
 
     def target_size(self, s, scale_mul=(1, 1), custom_sample=False, custom_img_size_idx=0, custom_image_size=None):
         """Size selection of sample_via_scale (models.py:554-565), int() truncation included."""
