@@ -8,8 +8,9 @@
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
  *     (PyTorch-ROCm tensors) unless marked "host"; the library never allocates or
- *     frees device memory and keeps no mutable global state (the opt-in
- *     sinddm_prof_* measurement hooks at the end are the only exception).
+ *     frees device memory and keeps no mutable global state.  It reads no
+ *     environment variable: kernel selection is fixed at compile time.  (The opt-in measurement
+ *     hooks live in sinddm_hip_debug.h and are not part of this contract.)
  *   - all tensors are fp32, NCHW, contiguous.  Timesteps are int64.
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no
  *     host synchronisation inside.  Re-entrant across streams.
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SINDDM_ABI_VERSION 1
+#define SINDDM_ABI_VERSION 2
 
 #define SINDDM_E_BADARG   (-1)  /* null pointer / non-positive size            */
 #define SINDDM_E_BADSHAPE (-2)  /* dim/channels not supported by the kernels   */
@@ -167,22 +168,6 @@ int sinddm_l1_loss_fwd_bwd(const float* noise, const float* eps, float* loss_out
 int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* ema, float step_size,
                          float beta1, float beta2, float eps, float bc2_sqrt, float ema_decay,
                          float reserved, int mode, int64_t n, void* stream);
-
-/* ---- measurement hooks (bench.py roofline leg) ----------------------------------------------
- * Between prof_begin and prof_end every MFMA conv launch is bracketed by hipEvents on the stream it
- * is launched on; prof_end synchronises those events and returns the summed kernel time (ms), the
- * number of launches and their algorithmic FLOPs (2*B*H*W*Cout*(9*Cin + Cin2)).  Process-global,
- * not thread-safe; off by default.  No reference counterpart (the reference has no profiling). */
-int sinddm_prof_begin(void);
-int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
-/* same, plus the FLOPs the matrix cores actually executed (Winograd F(2x2,3x3) launches execute 16/36
- * of their algorithmic FLOPs) */
-int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
-                     double* conv_exec_flops_total);
-/* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino_kernel), 2 = 1x1 convs,
- * 3 = direct 3x3 (conv_mfma_dma_kernel).  reset = 0 keeps the records so that several kinds can be queried. */
-int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total,
-                     double* exec_flops_total, int reset);
 
 #ifdef __cplusplus
 }

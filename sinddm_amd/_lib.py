@@ -51,6 +51,11 @@ def load() -> C.CDLL:
         raise SinddmError(
             f"{LIB_PATH} is missing: build it with `python -m sinddm_amd.build` (hipcc, gfx950). "
             "sinddm_amd has no CPU / PyTorch fallback for the hot path.")
+    from . import build as _build
+    try:
+        _build.verify()                      # a binary built from other sources than the ones beside it is refused
+    except RuntimeError as e:
+        raise SinddmError(str(e)) from None
     lib = C.CDLL(LIB_PATH)
     p, i, i64, f, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
     sig = {

@@ -1,15 +1,24 @@
-"""Builds libsinddm_hip.so (gfx950) in-tree with hipcc.  `python -m sinddm_amd.build`."""
+"""Builds libsinddm_hip.so (gfx950) in-tree with hipcc.  `python -m sinddm_amd.build [--force]`.
+
+The built library is git-ignored but travels to the GPU box with the source snapshot, so a stale binary is a real
+hazard: every build writes the SHA-256 of its inputs (all of csrc/, include/ and the compiler flags) next to the
+library, `needs_build()` / `verify()` compare it with the current sources, and `_lib.load()` refuses a library whose
+stamp does not match the sources it sits beside.
+"""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libsinddm_hip.so")
+STAMP = LIB + ".sha256"
 SOURCES = ["sinddm_fwd.hip", "sinddm_bwd.hip"]
-HEADERS = ["common.h", "plan.h", "conv_mfma.h", os.path.join("..", "..", "include", "sinddm_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 
 def _hipcc() -> str:
@@ -19,24 +28,53 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+def _inputs():
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip"))]
+    files += [os.path.join(INCLUDE, f) for f in sorted(os.listdir(INCLUDE)) if f.endswith(".h")]
+    return files
+
+
+def source_hash() -> str:
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in _inputs():
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stamp() -> str:
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
+    return not os.path.exists(LIB) or stamp() != source_hash()
+
+
+def verify() -> None:
+    """Raise if the library is missing or was built from other sources than the ones beside it."""
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+        raise RuntimeError(f"{LIB} is missing: run `python -m sinddm_amd.build`")
+    if stamp() != source_hash():
+        raise RuntimeError(f"{LIB} is stale (csrc/ or include/ changed since it was built): run `python -m sinddm_amd.build`")
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(HERE, "..", "include"), *srcs, "-o", LIB]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, *srcs, "-o", LIB]
     if verbose:
         print("[sinddm_amd.build]", " ".join(cmd), flush=True)
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -3,8 +3,36 @@
 #include <stdint.h>
 #include "plan.h"
 #include "../../include/sinddm_hip.h"
+#include "../../include/sinddm_hip_debug.h"
 
 namespace sinddm {
+
+// Kernel-selection switches are COMPILE-TIME macros (A/B builds: tools/build_variant.sh <name> -D...): the shipped
+// library reads no environment variable, so nothing outside the caller's arguments can change which kernel a call runs.
+#ifndef SINDDM_CONV_WINO      // 1: 3x3 convs (C_in >= 8) on the Winograd kernel, 0: direct implicit-GEMM kernel
+#define SINDDM_CONV_WINO 1
+#endif
+#ifndef SINDDM_CONV_VAR       // -1: pick 4- or 8-wave direct-conv workgroups per launch; 4 / 8: force
+#define SINDDM_CONV_VAR (-1)
+#endif
+#ifndef SINDDM_CONV_C3        // 1: dedicated VALU kernel for the C_in = 3 conv
+#define SINDDM_CONV_C3 1
+#endif
+#ifndef SINDDM_WGRAD_WINO     // 1: Winograd-domain 3x3 weight gradient
+#define SINDDM_WGRAD_WINO 1
+#endif
+#ifndef SINDDM_WGRAD_W3       // 1: 80x80-slab direct 3x3 weight gradient where the Winograd one does not apply
+#define SINDDM_WGRAD_W3 1
+#endif
+#ifndef SINDDM_WGRAD_W1       // 1: 80x80-slab 1x1 weight gradient
+#define SINDDM_WGRAD_W1 1
+#endif
+#ifndef SINDDM_WGRAD_STAGE    // 1: coalesced [co][tap][ci] staging slab for the 3x3 weight-gradient atomics
+#define SINDDM_WGRAD_STAGE 1
+#endif
+#ifndef SINDDM_WGRAD_ABL      // timing ablation bits of the weight-gradient kernels (results WRONG when != 0)
+#define SINDDM_WGRAD_ABL 0
+#endif
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;

@@ -296,16 +296,9 @@ struct ConvProfiler {
 };
 ConvProfiler& conv_profiler();
 
-// tuning knob (read once): SINDDM_CONV_VAR = 4 forces 4-wave workgroups on 4x32 tiles, 8 forces 8-wave
-// workgroups on 8x32 tiles; default (-1) picks per launch
-inline int conv_tuning_var() {
-    static int v = [] {
-        const char* e = getenv("SINDDM_CONV_VAR");
-        const int x = e ? atoi(e) : -1;
-        return (x == 4 || x == 8) ? x : -1;
-    }();
-    return v;
-}
+// SINDDM_CONV_VAR (compile time, common.h) = 4 forces 4-wave workgroups on 4x32 tiles, 8 forces 8-wave workgroups on
+// 8x32 tiles; default (-1) picks per launch
+inline int conv_tuning_var() { return (SINDDM_CONV_VAR == 4 || SINDDM_CONV_VAR == 8) ? SINDDM_CONV_VAR : -1; }
 
 template <int MT, int NT, int PIN, int WV>
 inline void conv_launch_dma_t(const ConvArgs& a, unsigned grid, hipStream_t st) {

@@ -362,11 +362,11 @@ inline void conv_wino_launch_c(const ConvArgs& a, unsigned grid, int ipx, int wp
 }
 
 // channels per chunk: 16 (measured: 32-channel chunks = half the barriers, but only one M tile per epilogue pass
-// fits in LDS then; 2 % slower end to end).  SINDDM_WINO_CPC=2 selects the 32-channel variant for A/B runs.
-inline int wino_cpc() {
-    static int v = [] { const char* e = getenv("SINDDM_WINO_CPC"); return (e && atoi(e) == 2) ? 2 : 1; }();
-    return v;
-}
+// fits in LDS then; 2 % slower end to end).  -DSINDDM_WINO_CPC=2 selects the 32-channel variant for A/B builds.
+#ifndef SINDDM_WINO_CPC
+#define SINDDM_WINO_CPC 1
+#endif
+inline int wino_cpc() { return SINDDM_WINO_CPC == 2 ? 2 : 1; }
 
 template <int MT, int NTR>
 inline void conv_wino_launch_a(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
@@ -433,12 +433,6 @@ inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     return 0;
 }
 
-inline bool wino_enabled() {
-    static int v = [] {
-        const char* e = getenv("SINDDM_CONV_WINO");
-        return e ? atoi(e) : 1;
-    }();
-    return v != 0;
-}
+inline bool wino_enabled() { return SINDDM_CONV_WINO != 0; }
 
 }  // namespace sinddm

@@ -506,13 +506,13 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
     a.zero = zero;
     a.dout = dout; a.in = in; a.gw = gw; a.gb = gb;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    static const int abl = getenv("SINDDM_WGRAD_ABL") ? atoi(getenv("SINDDM_WGRAD_ABL")) : 0;
-    static const int w3 = getenv("SINDDM_WGRAD_W3") ? atoi(getenv("SINDDM_WGRAD_W3")) : 1;
+    constexpr int abl = SINDDM_WGRAD_ABL;
+    constexpr int w3 = SINDDM_WGRAD_W3;
     a.abl = abl;
     a.tilesX = (W + WG_TW - 1) / WG_TW;
     a.tilesY = (H + WG_TH - 1) / WG_TH;
     a.ntiles = B * a.tilesX * a.tilesY;
-    static const int ww = getenv("SINDDM_WGRAD_WINO") ? atoi(getenv("SINDDM_WGRAD_WINO")) : 1;
+    constexpr int ww = SINDDM_WGRAD_WINO;
     if (taps == 9 && Cout % WW_CO == 0 && Cin >= 16 && ww && scr) {
         // Winograd-domain weight gradient (2.25x fewer MFMAs); always through the [co][tap][ci] staging slab
         if ((size_t)WW_CO * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
@@ -540,7 +540,7 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         SINDDM_LAUNCH_CHECK();
         return 0;
     }
-    static const int w1 = getenv("SINDDM_WGRAD_W1") ? atoi(getenv("SINDDM_WGRAD_W1")) : 1;
+    constexpr int w1 = SINDDM_WGRAD_W1;
     if (taps == 1 && Cout % W1_C == 0 && w1) {
         if ((size_t)W1_C * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
         a.coblks = Cout / W1_C;
@@ -571,7 +571,7 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         if (S > cap) S = cap;
         a.S = S;
         constexpr size_t lds = (size_t)2 * W3_BUF * sizeof(float);
-        static const int stage = getenv("SINDDM_WGRAD_STAGE") ? atoi(getenv("SINDDM_WGRAD_STAGE")) : 1;
+        constexpr int stage = SINDDM_WGRAD_STAGE;
         const int n = Cout * Cin * 9;
         if (scr && stage) {
             hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);

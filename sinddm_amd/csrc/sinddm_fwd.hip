@@ -646,7 +646,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
         c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
-        static const int c3 = getenv("SINDDM_CONV_C3") ? atoi(getenv("SINDDM_CONV_C3")) : 1;
+        constexpr int c3 = SINDDM_CONV_C3;
         if (wino && b.pk_wc1 >= 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);

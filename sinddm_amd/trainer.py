@@ -177,41 +177,46 @@ class MultiscaleTrainer(object):
         else:
             self.ema.update_model_average(self.ema_model, self.model)
 
-    def save(self, milestone):
-        data = {
-            'step': self.step,
-            'model': self.model.state_dict(),
-            'ema': self.ema_model.state_dict(),
-            'sched': self.scheduler.state_dict(),
-            'running_loss': self.running_loss,
-            'running_scale': self.running_scale,
-        }
+    # ---- checkpoints: same file layout as the reference (trainer.py:161-187) so its model-N.pt files interoperate ----
+    _CKPT_KEYS = ('step', 'model', 'ema', 'sched', 'running_loss', 'running_scale')
+
+    def _ckpt_path(self, milestone) -> str:
+        return str(self.results_folder / f'model-{milestone}.pt')
+
+    def _checkpoint_state(self) -> dict:
+        state = dict(zip(self._CKPT_KEYS, (self.step, self.model.state_dict(), self.ema_model.state_dict(),
+                                           self.scheduler.state_dict(), self.running_loss, self.running_scale)))
         if isinstance(self.opt, FusedAdam):
-            data['opt'] = self.opt.state_dict()       # extra key (the reference omits Adam state)
-        torch.save(data, str(self.results_folder / f'model-{milestone}.pt'))
+            state['opt'] = self.opt.state_dict()       # extra key: the reference drops the Adam moments on save
+        return state
+
+    def _plot_running_loss(self) -> None:
+        """running_loss.png next to the checkpoints (the reference plots the same curve); best effort, headless."""
         try:
             import matplotlib
             matplotlib.use('Agg')
             from matplotlib import pyplot as plt
-            plt.rcParams['figure.figsize'] = [16, 8]
-            plt.plot(self.running_loss)
-            plt.grid(True)
-            plt.ylim((0, 0.2))
-            plt.savefig(str(self.results_folder / 'running_loss'))
-            plt.clf()
         except Exception:
-            pass
+            return
+        fig, ax = plt.subplots(figsize=(16, 8))
+        ax.plot(self.running_loss)
+        ax.set_ylim(0, 0.2)
+        ax.grid(True)
+        fig.savefig(str(self.results_folder / 'running_loss'))
+        plt.close(fig)
+
+    def save(self, milestone):
+        torch.save(self._checkpoint_state(), self._ckpt_path(milestone))
+        self._plot_running_loss()
 
     def load(self, milestone):
-        data = torch.load(str(self.results_folder / f'model-{milestone}.pt'), map_location=self.device,
-                          weights_only=False)
-        self.step = data['step']
-        self.model.load_state_dict(data['model'])
-        self.ema_model.load_state_dict(data['ema'])
-        self.scheduler.load_state_dict(data['sched'])
-        self.running_loss = data['running_loss']
-        if 'opt' in data and isinstance(self.opt, FusedAdam):
-            self.opt.load_state_dict(data['opt'])
+        state = torch.load(self._ckpt_path(milestone), map_location=self.device, weights_only=False)
+        self.model.load_state_dict(state['model'])
+        self.ema_model.load_state_dict(state['ema'])
+        self.scheduler.load_state_dict(state['sched'])
+        self.step, self.running_loss = state['step'], state['running_loss']
+        if isinstance(self.opt, FusedAdam) and 'opt' in state:
+            self.opt.load_state_dict(state['opt'])
 
     def _pick_scale(self, weights: torch.Tensor) -> int:
         if self.scale_fn is not None:
@@ -276,137 +281,123 @@ class MultiscaleTrainer(object):
     def sample_scales(self, scale_mul=None, batch_size=16, custom_sample=False, custom_image_size_idxs=None,
                       custom_scales=None, image_name='', start_noise=True, custom_t_list=None, desc=None,
                       save_unbatched=True, save_images=True) -> List[torch.Tensor]:
-        """Drive the sampler over all scales (trainer.py:226-285).  Under torch.distributed the batch is
-        sharded over ranks as independent chains and gathered with one all-gather per scale
-        (RCCL over xGMI on MI355X); returns the list of per-scale (global) sample batches."""
-        if desc is None:
-            desc = f'sample_{str(datetime.datetime.now()).replace(":", "_")}'
-        if self.ema_model.reblurring:
-            desc = desc + '_rblr'
-        if self.ema_model.sample_limited_t:
-            desc = desc + '_t_lmtd'
-        if custom_t_list is None:
-            custom_t_list = self.ema_model.num_timesteps_ideal[1:]
-        if custom_scales is None:
-            custom_scales = [*range(self.n_scales)]
-            n_scales = self.n_scales
-        else:
-            n_scales = len(custom_scales)
-        if custom_image_size_idxs is None:
-            custom_image_size_idxs = [*range(self.n_scales)]
-        final_results_folder = Path(str(self.results_folder / 'final_samples'))
+        """Drive the sampler over all scales (behaviour of reference trainer.py:226-285).  Under torch.distributed the
+        batch is sharded over ranks as independent chains and gathered with one all-gather per scale (RCCL over xGMI
+        on MI355X); returns the list of per-scale (global) sample batches."""
+        em = self.ema_model
+        # --- what to run: one (scale, size index, start timestep) triple per stage ---
+        scales = list(range(self.n_scales)) if custom_scales is None else list(custom_scales)
+        size_idx = list(range(self.n_scales)) if custom_image_size_idxs is None else list(custom_image_size_idxs)
+        t_starts = list(em.num_timesteps_ideal[1:]) if custom_t_list is None else list(custom_t_list)
+        stretch = (1, 1) if scale_mul is None else scale_mul
+        first_size = None
         if scale_mul is not None:
-            scale_0_size = (int(self.model.image_sizes[custom_image_size_idxs[0]][0] * scale_mul[0]),
-                            int(self.model.image_sizes[custom_image_size_idxs[0]][1] * scale_mul[1]))
-        else:
-            scale_0_size = None
-            scale_mul = (1, 1)
-        t_list = [self.ema_model.num_timesteps_trained[0]] + list(custom_t_list)
-        res_sub_folder = '_'.join(str(e) for e in t_list)
-
+            h0, w0 = self.model.image_sizes[size_idx[0]]
+            first_size = (int(h0 * scale_mul[0]), int(w0 * scale_mul[1]))
+        # --- where the PNGs go (names as the reference writes them) ---
+        tag = desc if desc is not None else f'sample_{str(datetime.datetime.now()).replace(":", "_")}'
+        tag += '_rblr' if em.reblurring else ''
+        tag += '_t_lmtd' if em.sample_limited_t else ''
+        t_tag = '_'.join(str(e) for e in [em.num_timesteps_trained[0]] + t_starts)
+        out_dir = Path(str(self.results_folder / 'final_samples'))
+        writer = sdist.rank() == 0 and save_images
+        if writer:
+            out_dir.mkdir(parents=True, exist_ok=True)
+        # --- this rank's chains ---
         if batch_size < sdist.world_size():
             raise ValueError(f'sample_scales: batch_size={batch_size} < world_size={sdist.world_size()} would leave ranks '
                              'without chains (every rank must join the all-gather)')
-        local_b = sdist.local_batch(batch_size)          # this rank's independent chains
-        is_main = sdist.rank() == 0
-        if save_images and is_main:
-            final_results_folder.mkdir(parents=True, exist_ok=True)
-
-        local_samples: List[torch.Tensor] = []
-        gathered: List[torch.Tensor] = []
-        final_img = None
-        for i in range(n_scales):
-            if start_noise and i == 0:
-                cur = self.ema_model.sample(batch_size=local_b, scale_0_size=scale_0_size, s=custom_scales[i])
-            elif i == 0:
-                orig = Image.open((self.input_paths[custom_scales[i]] + '/' + image_name)).convert('RGB')
-                cur = image_to_tensor(orig).repeat(local_b, 1, 1, 1).to(self.device)
-            else:
-                cur = self.ema_model.sample_via_scale(local_b, local_samples[i - 1], s=custom_scales[i],
-                                                      scale_mul=scale_mul, custom_sample=custom_sample,
-                                                      custom_img_size_idx=custom_image_size_idxs[i],
-                                                      custom_t=custom_t_list[int(custom_scales[i]) - 1])
-            local_samples.append(cur)
-            full = sdist.gather_batch(cur, batch_size)   # no-op on a single process
-            gathered.append(full)
-            if save_images and is_main:
-                final_img = (full + 1) * 0.5
-                save_image(final_img, str(final_results_folder / res_sub_folder)
-                           + f'_out_s{i}_{desc}_sm_{scale_mul[0]}_{scale_mul[1]}.png', nrow=4)
-        if save_images and save_unbatched and is_main and final_img is not None:
-            unb = Path(str(self.results_folder / f'final_samples_unbatched_{desc}'))
-            unb.mkdir(parents=True, exist_ok=True)
-            for b in range(final_img.shape[0]):
-                save_image(final_img[b], str(unb / res_sub_folder) + f'_out_b{b}.png')
-        return gathered
+        mine = sdist.local_batch(batch_size)
+        per_scale, cur, shown = [], None, None
+        for stage, s in enumerate(scales):
+            if stage > 0:
+                cur = em.sample_via_scale(mine, cur, s=s, scale_mul=stretch, custom_sample=custom_sample,
+                                          custom_img_size_idx=size_idx[stage], custom_t=t_starts[int(s) - 1])
+            elif start_noise:
+                cur = em.sample(batch_size=mine, scale_0_size=first_size, s=s)
+            else:                                   # start from the training image of that scale instead of noise
+                seed_img = Image.open(self.input_paths[s] + '/' + image_name).convert('RGB')
+                cur = image_to_tensor(seed_img).repeat(mine, 1, 1, 1).to(self.device)
+            whole = sdist.gather_batch(cur, batch_size)          # identity on a single process
+            per_scale.append(whole)
+            if writer:
+                shown = (whole + 1) * 0.5
+                save_image(shown, str(out_dir / t_tag) + f'_out_s{stage}_{tag}_sm_{stretch[0]}_{stretch[1]}.png', nrow=4)
+        if writer and save_unbatched and shown is not None:
+            single_dir = Path(str(self.results_folder / f'final_samples_unbatched_{tag}'))
+            single_dir.mkdir(parents=True, exist_ok=True)
+            for b, one in enumerate(shown):
+                save_image(one, str(single_dir / t_tag) + f'_out_b{b}.png')
+        return per_scale
 
     # ---- application drivers of the reference that run entirely on the hot path (SURVEY 8(f) row 4) ----
+    def _i2i_source(self, input_folder, input_file, mask, hist_ref_path, image_name, use_hist, auto_scale, mode, device):
+        """Host-side preparation of harmonization / style transfer: the (optionally shrunk, optionally histogram
+        matched) source image as a [-1,1] tensor, and the blend mask (1 = keep the sample everywhere)."""
+        import os
+        from .functions import dilate_mask, match_histograms
+        src = Image.open(os.path.join(input_folder, input_file)).convert("RGB")
+        size = src.size
+        if auto_scale is not None:
+            shrink = np.sqrt((size[0] * size[1]) / auto_scale)
+            if shrink > 1:
+                size = (int(size[0] / shrink), int(size[1] / shrink))
+                src = src.resize(size, Image.LANCZOS)
+        keep = 1
+        if mode == 'harmonization':
+            m = Image.open(os.path.join(input_folder, mask)).convert("RGB").resize(size, Image.LANCZOS)
+            keep = torch.from_numpy(dilate_mask(image_to_tensor_01(m), mode=mode)).to(device=device, dtype=torch.float32)
+        if use_hist:
+            ref = Image.open(hist_ref_path + image_name.rsplit(".", 1)[0] + '.png').convert("RGB")
+            src = Image.fromarray(match_histograms(image=np.array(src), reference=np.array(ref), channel_axis=2))
+        return image_to_tensor(src), keep
+
     @torch.no_grad()
     def image2image(self, input_folder='', input_file='', mask='', hist_ref_path='', image_name='', start_s=1,
                     custom_t=None, batch_size=16, scale_mul=(1, 1), device=None, use_hist=False, save_unbatched=True,
                     auto_scale=None, mode=None, save_images=True):
-        """Harmonization / style transfer (trainer.py:287-362): re-noise the input image at scale `start_s` to
-        `custom_t[start_s]` and denoise it through the remaining scales with the trained model.  Returns the list of
-        per-scale sample batches (the reference only writes PNGs)."""
+        """Harmonization / style transfer (behaviour of reference trainer.py:287-362): the input image is re-noised at
+        scale `start_s` to `custom_t[start_s]` and denoised through the remaining scales by the trained model; in
+        harmonization mode the result is pasted into the input through the dilated mask.  Returns the per-scale sample
+        batches (the reference only writes PNGs)."""
         import os
-        from .functions import dilate_mask, match_histograms
         device = self.device if device is None else device
-        if custom_t is None:
-            custom_t = self.ema_model.num_timesteps_ideal
-        input_img = Image.open(os.path.join(input_folder, input_file)).convert("RGB")
-        image_size = input_img.size
-        if auto_scale is not None:
-            scaler = np.sqrt((image_size[0] * image_size[1]) / auto_scale)
-            if scaler > 1:
-                image_size = (int(image_size[0] / scaler), int(image_size[1] / scaler))
-                input_img = input_img.resize(image_size, Image.LANCZOS)
-        if mode == 'harmonization':
-            mask_img = Image.open(os.path.join(input_folder, mask)).convert("RGB").resize(image_size, Image.LANCZOS)
-            mask_img = dilate_mask(image_to_tensor_01(mask_img), mode=mode)
-            mask_img = torch.from_numpy(mask_img).to(device=device, dtype=torch.float32)
-        else:
-            mask_img = 1
-        if use_hist:
-            image_name = image_name.rsplit(".", 1)[0] + '.png'
-            ref0 = Image.open(hist_ref_path + image_name).convert("RGB")
-            input_img = Image.fromarray(match_histograms(image=np.array(input_img), reference=np.array(ref0),
-                                                         channel_axis=2))
-        input_img_tensor = image_to_tensor(input_img)
-        input_size = torch.tensor(input_img_tensor.shape[1:])
-        input_img_batch = input_img_tensor.repeat(batch_size, 1, 1, 1).to(device)
-
-        final_results_folder = Path(str(self.results_folder / 'i2i_final_samples'))
+        em = self.ema_model
+        t_starts = em.num_timesteps_ideal if custom_t is None else custom_t
+        src, keep = self._i2i_source(input_folder, input_file, mask, hist_ref_path, image_name, use_hist, auto_scale,
+                                     mode, device)
+        src_hw = torch.tensor(src.shape[1:])
+        batch = src.repeat(batch_size, 1, 1, 1).to(device)
+        if start_s > 0:
+            # no blur mixing at the scale the chain starts from: its gamma row is zeroed in place, as the reference does
+            em.gammas[start_s - 1].clamp_(0, 0)
+        stamp = str(datetime.datetime.now()).replace(":", "_")
+        t_tag = '_'.join(str(e) for e in t_starts)
+        out_dir = Path(str(self.results_folder / 'i2i_final_samples'))
         if save_images:
-            final_results_folder.mkdir(parents=True, exist_ok=True)
-        final_img = None
-        t_string = '_'.join(str(e) for e in custom_t)
-        time = str(datetime.datetime.now()).replace(":", "_")
-        if start_s > 0:      # the starting scale has no mixing between blurry and clean images (trainer.py:326-327)
-            self.ema_model.gammas[start_s - 1].clamp_(0, 0)
-        samples_from_scales = []
-        for i in range(self.n_scales - start_s):
-            s = i + start_s
-            ds_factor = self.scale_factor ** (self.n_scales - s - 1)
-            cur_size = input_size / ds_factor
-            cur_size = (int(cur_size[0].item()), int(cur_size[1].item()))
-            src = input_img_batch if i == 0 else samples_from_scales[i - 1]
-            samples_from_scales.append(self.ema_model.sample_via_scale(batch_size, src, s=s, custom_t=custom_t[s],
-                                                                       scale_mul=scale_mul, custom_image_size=cur_size))
-            final_img = (samples_from_scales[i] + 1) * 0.5
-            if i == self.n_scales - start_s - 1:
-                denorm = ((input_img_batch + 1) * 0.5).clamp_(0.0, 1.0)
-                final_img = mask_img * final_img + (1 - mask_img) * denorm
+            out_dir.mkdir(parents=True, exist_ok=True)
+        last = self.n_scales - 1
+        outs, shown = [], None
+        for s in range(start_s, self.n_scales):
+            # target size of this scale: the (possibly shrunk) input divided by scale_factor^(scales still to go)
+            hw = src_hw / (self.scale_factor ** (last - s))
+            target = (int(hw[0].item()), int(hw[1].item()))
+            outs.append(em.sample_via_scale(batch_size, batch if not outs else outs[-1], s=s, custom_t=t_starts[s],
+                                            scale_mul=scale_mul, custom_image_size=target))
+            shown = (outs[-1] + 1) * 0.5
+            if s == last:
+                shown = keep * shown + (1 - keep) * ((batch + 1) * 0.5).clamp_(0.0, 1.0)
             if save_images:
-                name = input_file.rsplit(".", 1)[0]
-                save_image(final_img, str(final_results_folder / f'{name}_i2i_s_{start_s + i}_t_{t_string}_hist_'
-                                          f'{"on" if use_hist else "off"}_{time}.png'), nrow=4)
+                stem = input_file.rsplit(".", 1)[0]
+                save_image(shown, str(out_dir / f'{stem}_i2i_s_{s}_t_{t_tag}_hist_{"on" if use_hist else "off"}_{stamp}.png'),
+                           nrow=4)
         if save_images and save_unbatched:
-            unb = Path(str(self.results_folder / f'unbatched_i2i_s{start_s}_t_{t_string}_{time}'))
-            unb.mkdir(parents=True, exist_ok=True)
+            single_dir = Path(str(self.results_folder / f'unbatched_i2i_s{start_s}_t_{t_tag}_{stamp}'))
+            single_dir.mkdir(parents=True, exist_ok=True)
             for b in range(batch_size):
-                save_image(final_img[b], os.path.join(unb, input_file + f'_out_b{b}_i2i.png'))
-        self.last_i2i_image = final_img
-        return samples_from_scales
+                save_image(shown[b], os.path.join(single_dir, input_file + f'_out_b{b}_i2i.png'))
+        self.last_i2i_image = shown
+        return outs
 
     @torch.no_grad()
     def roi_guided_sampling(self, custom_t_list=None, target_roi=None, roi_bb_list=None, save_unbatched=False,

@@ -12,9 +12,26 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _header_symbols():
+    """Every function include/*.h declares (the boundary header and the debug-hook header)."""
+    syms = set()
+    for name in sorted(os.listdir(os.path.join(REPO, "include"))):
+        if not name.endswith(".h"):
+            continue
+        txt = open(os.path.join(REPO, "include", name)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b(sinddm_[a-z0-9_]+)\s*\(", txt))
+    return sorted(syms)
+
+
+def test_boundary_header_has_no_global_state_hooks():
+    """The measurement hooks (process-global event table) are declared in sinddm_hip_debug.h only, and the library
+    sources read no environment variable."""
     txt = open(os.path.join(REPO, "include", "sinddm_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sinddm_[a-z0-9_]+)\s*\(", txt)))
+    assert "sinddm_prof_" not in re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    csrc = os.path.join(REPO, "sinddm_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".h", ".hip")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 def test_header_and_binding_agree():
@@ -27,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _header_symbols():
         assert hasattr(lib, name), name
-    assert lib.sinddm_abi_version() == 1
+    assert lib.sinddm_abi_version() == 2
     assert not _lib.missing_symbols()
 
 

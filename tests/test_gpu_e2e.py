@@ -295,3 +295,41 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
     assert line["full_sample"]["images"] == 2 * line["config"]["batch_per_gpu"] and line["full_sample"]["finite"]
     assert 0 < line["roofline"]["frac"] <= 1.0
+
+
+def test_integration_option_b_snippet():
+    """INTEGRATION.md option B, executed as written: the reference-side ctypes stub (extracted from the markdown) wraps
+    a network with the reference's parameter order and must reproduce the oracle; plugged into
+    MultiScaleGaussianDiffusion as a FOREIGN denoise_fn it goes through the generic plug point (models.py:356)."""
+    import re
+    from sinddm_amd.configs import CONFIGS
+    from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(repo, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", md, flags=re.S)
+    code = [b for b in blocks if "class HipSinDDMNet" in b]
+    assert len(code) == 1
+    code = code[0].replace('C.CDLL("libsinddm_hip.so")', f'C.CDLL({os.path.join(repo, "sinddm_amd", "libsinddm_hip.so")!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:option-B", "exec"), ns)
+    dim = 32
+    ref_like = SinDDMNet(dim=dim, multiscale=True, device="cpu")          # parameters in the reference's order
+    ref_like.load_state_dict(closed_form_state_dict(dim))
+    hip = ns["HipSinDDMNet"](ref_like, dim)
+    sd = closed_form_state_dict(dim)
+    x = hash_randn((2, 3, 37, 45), 5)
+    t = torch.tensor([3, 77])
+    y = hip(x.cuda(), t.cuda(), scale=1)
+    assert rel_l2(y.cpu(), O.net_forward(sd, x, t, 1)) < 1e-5
+    # as a foreign denoiser inside the diffusion class
+    meta = CONFIGS["C1"]
+    d = MultiScaleGaussianDiffusion(hip, n_scales=3, scale_factor=meta["scale_factor"], image_sizes=meta["sizes"],
+                                    timesteps=meta["T"], train_full_t=True, scale_losses=meta["rescale_losses"],
+                                    loss_factor=1, loss_type="l1", device="cuda:0", reblurring=True, omega=0).to("cuda:0")
+    sched = O.make_schedule(meta["T"], 3, meta["rescale_losses"], 1, train_full_t=True)
+    H, W = d.image_sizes[1]
+    xs, xt, z = hash_randn((2, 3, H, W), 6), hash_randn((2, 3, H, W), 7) * 0.5, hash_randn((2, 3, H, W), 8)
+    d.img_prev_upsample = xt.cuda()
+    d.noise_fn = lambda kind, shape, s, tt, dev: z.to(dev)
+    got = d.p_sample(xs.cuda(), torch.full((2,), 20, device="cuda:0", dtype=torch.long), 1)
+    assert rel_l2(got.cpu(), O.p_sample(sched, sd, xs, 20, 1, z, xt)) < 1e-5
