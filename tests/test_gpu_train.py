@@ -197,3 +197,32 @@ def test_second_forward_before_backward_raises():
     y2.sum().backward()
     with pytest.raises(_lib.SinddmError):
         y1.sum().backward()
+
+
+def test_net_backward_full_size_vs_oracle_autograd():
+    """The training shape of config C2: finest scale 186x248, dim = 160 (batch 2 bounds the oracle's CPU autograd to
+    ~20 s; samples are independent in every kernel).  All 52 parameter gradients + the input gradient."""
+    from sinddm_amd.models import SinDDMNet
+    dim, B, H, W = 160, 2, 186, 248
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    net.bind_grads()
+    net.flat_grads.zero_()
+    x = hash_randn((B, 3, H, W), 15)
+    gy = hash_randn((B, 3, H, W), 16) / (B * 3 * H * W)         # the scale an L1-mean loss hands to the net
+    t = torch.tensor([731, 12])
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd, t.to(DEV), scale=4)
+    y.backward(gy.to(DEV))
+    sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
+    xc = x.clone().requires_grad_(True)
+    yc = O.net_forward(sd, xc, t, 4)
+    yc.backward(gy)
+    assert rel_l2(y.detach().cpu(), yc.detach()) < 1e-5
+    assert rel_l2(xd.grad.cpu(), xc.grad) < 5e-5
+    worst = ("", 0.0)
+    for name, p in net.named_parameters():
+        err = rel_l2(p.grad.cpu(), sd[name].grad)
+        worst = max(worst, (name, err), key=lambda v: v[1])
+        assert err < 3e-4, (name, err)
+    print("full-size backward: worst rel-L2 gradient error", worst)
