@@ -39,6 +39,7 @@ struct ConvArgs {
     int nch3, nch1;
     int tilesX, tilesY, ntiles, tiles_per_xcd;
     int coblks;
+    int mtp;             // (Winograd kernel) m-tiles per PACKED output-channel block; 0 = same as the kernel's MT
     int act;             // 0 none, 1 GELU, 2 multiply by GELU'(aux)
 };
 

@@ -167,7 +167,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         if ((W2_ABL & 2) && g > 0) return;
         const bool wrap = g >= nks_total;
         const int gg = wrap ? 0 : g;
-        const int so = (((wrap ? ncb : cb) * nch + (gg >> 2)) * 4 + wi) * (4096 * MT) + (gg & 3) * (1024 * MT) + mt * 1024;
+        // the packed image is blocked by p.mtp m-tiles per output-channel block; an item covers MT of them (MT == p.mtp
+        // for the big launches, MT = 1 when a launch has too few tiles to fill the chip with whole blocks)
+        const int mg = (wrap ? ncb : cb) * MT + mt;              // global m-tile
+        const int pcb = mg / p.mtp, pmt = mg - pcb * p.mtp;
+        const int so = ((pcb * nch + (gg >> 2)) * 4 + wi) * (4096 * p.mtp) + (gg & 3) * (1024 * p.mtp) + pmt * 1024;
         a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
     };
     // Barriers are written in assembly: hipcc puts a full `s_waitcnt vmcnt(0)` in front of every s_barrier on gfx9,
@@ -580,6 +584,14 @@ inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     a.tilesY = (a.H + W2_TH - 1) / W2_TH;
     a.ntiles = a.B * a.tilesX * a.tilesY;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    // Small launches (coarse pyramid scales at small batch): with whole 80-channel blocks there are fewer work items
+    // than CUs and every item walks the full reduction alone -- one m-tile per item gives 5x the items at a fifth of
+    // the latency each (the packed weight image is addressed by global m-tile, so it serves both).
+    a.mtp = mt;
+    if (mt > 1 && a.ntiles * a.coblks < wino2_cu_count()) {
+        a.coblks *= mt;
+        mt = 1;
+    }
     // persistent launch: two 4-wave workgroups per CU, each walking its share of the XCD's work items
     const int ipx = a.tiles_per_xcd * a.coblks;                  // work items per XCD
 #ifdef W2_ONE_WG
