@@ -127,6 +127,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     constexpr unsigned OOB = 0x40000000u;
     unsigned goff;                                  // this lane's 16-byte group of the halo tile (per item)
     bool cm[4];                                     // patch column c of this lane's tile column lies inside the image
+    bool cmn[4];                                    // ... for the item whose raw tile is being staged (the next one)
     auto make_goff = [&](const Wino2Item& it) {
         const int row = lane / W2_GRP, grp = lane - row * W2_GRP;
         const int gy = it.y0 + row - 1, gx = it.x0 - 4 + 4 * grp;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         // a group that starts inside the image may run past its right edge (into the next row): those columns are
         // replaced by the zero padding when the patch is read
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cm[c] = it.x0 + 2 * l16 - 1 + c < W;
+        for (int c = 0; c < 4; ++c) cmn[c] = it.x0 + 2 * l16 - 1 + c < W;
     };
     // `valid` = false issues the same instructions with empty descriptors (zero fill): the instruction stream of a
     // chunk is the same for every chunk, so the compiler's vmcnt bookkeeping is exact (no control-flow merge)
@@ -159,6 +160,13 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     const __amdgpu_buffer_rsrc_t rsw =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFF0, 0x00020000);
     const int wlane = lane * 16;
+    // byte offset of (item block cb, chunk 0, this wave's frequency row, k-step 0, m-tile 0) in the packed image -- the
+    // one integer division of the weight addressing, once per item instead of once per load
+    auto wbase = [&](int cb) -> int {
+        const int mg = cb * MT;                                    // first global m-tile of the item (MT divides p.mtp)
+        const int pcb = mg / p.mtp, pmt = mg - pcb * p.mtp;
+        return (pcb * nch * 4 + wi) * (4096 * p.mtp) + pmt * 1024;
+    };
     f32x4 a[MT];                                                   // A operands of the current k-step
     // g = k-step index inside the item; g == nks_total means "k-step 0 of the next item" (output-channel block ncb):
     // the weight stream, like the raw-tile stream, runs across items without a branch inside a k-step -- a chunk stays
@@ -169,9 +177,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         const int gg = wrap ? 0 : g;
         // the packed image is blocked by p.mtp m-tiles per output-channel block; an item covers MT of them (MT == p.mtp
         // for the big launches, MT = 1 when a launch has too few tiles to fill the chip with whole blocks)
-        const int mg = (wrap ? ncb : cb) * MT + mt;              // global m-tile
-        const int pcb = mg / p.mtp, pmt = mg - pcb * p.mtp;
-        const int so = ((pcb * nch + (gg >> 2)) * 4 + wi) * (4096 * p.mtp) + (gg & 3) * (1024 * p.mtp) + pmt * 1024;
+        // (`cb` / `ncb` arrive already split into packed block and first packed m-tile: wbase())
+        const int wb = wrap ? ncb : cb;
+        const int so = wb + (gg >> 2) * (4 * 4096) * p.mtp + (gg & 3) * (1024 * p.mtp) + mt * 1024;
         a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
     };
     // Barriers are written in assembly: hipcc puts a full `s_waitcnt vmcnt(0)` in front of every s_barrier on gfx9,
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             }
         }
     };
-    auto transform = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4]) {
+    auto transform = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4], const bool (&cm)[4]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (W2_ABL & 4) { v[nt][0] = ra[nt][0]; v[nt][1] = rb[nt][0]; v[nt][2] = ra[nt][2]; v[nt][3] = rb[nt][1]; continue; }
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         (row ? rb : ra)[nt][half * 2 + 1] = src[1];
     };
     float tr_[4];                                   // row-combined patch of the tile-row being transformed
-    auto transform_piece = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4], int q) {
+    auto transform_piece = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4], int q, const bool (&cm)[4]) {
         const int nt = q >> 2;
         if (W2_ABL & 16) { if ((q & 3) == 0) { v[nt][0] = ra[nt][0]; v[nt][1] = rb[nt][1]; v[nt][2] = ra[nt][2]; v[nt][3] = rb[nt][3]; } return; }
         switch (q & 3) {
@@ -272,16 +280,19 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     }
 #endif
     make_goff(it);
-    issue(it.b, 0, true, smem);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) load_w(mt, it.cb, it.cb, 0);
+    for (int c = 0; c < 4; ++c) cm[c] = cmn[c];
+    issue(it.b, 0, true, smem);
+    int wb_it = wbase(it.cb);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) load_w(mt, wb_it, wb_it, 0);
     __syncthreads();
     int nb = 0;                                    // raw buffer holding the current chunk (runs across items)
     float v[2][NT][4];                             // B operands, double buffered by k-step parity (runs across items)
     {
         f32x4 ra[NT], rb[NT];
         read_raw(smem, ra, rb);
-        transform(ra, rb, v[0]);
+        transform(ra, rb, v[0], cm);
     }
 #ifdef W2_TIMING
     int dbg_item = 0;
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         l += 1;
         const bool have_next = decode(l, nx);
         if (!have_next) nx = it;
+        const int wb_nx = wbase(nx.cb);
 #ifdef W2_TIMING
         const bool dbg = (blockIdx.x == 8 || blockIdx.x == 8 + 8 * 32) && dbg_item < 4 && lane == 0;
         if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 39) * 4 + wi] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
@@ -342,6 +354,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 }
                 const float* rsrc_ = ks < 3 ? cur + (ks + 1) * 4 * W2_PS : nxt;
                 f32x4 ra[NT], rb[NT];
+                // the B operands built in k-step 3 belong to the NEXT chunk: in the last chunk of an item that is the next
+                // item's tile, whose right-edge column masks differ
+                bool mk[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) mk[cc] = (ks == 3 && last) ? cmn[cc] : cm[cc];
                 if constexpr (MT >= 3) {
                     // Fine-grained, pinned order (a sched_barrier after every piece): one MFMA occupies the matrix pipe
                     // for 32 cycles, and whatever this wave issues in that shadow is free -- whatever it issues in a
@@ -361,10 +378,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                             acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
                             if (mt == 0) read_piece(rsrc_, ra, rb, q);
-                            if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q);
+                            if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q, mk);
                             if (mt == 0 || mt == 2) __builtin_amdgcn_sched_barrier(0);
                         }
-                        load_w(mt, it.cb, nx.cb, g + 1);
+                        load_w(mt, wb_it, wb_nx, g + 1);
                         // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
                         // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Spread out on purpose: a wave
                         // BLOCKS at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy --
@@ -389,12 +406,12 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     read_raw(rsrc_, ra, rb);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        if (mt == MT - 1) transform(ra, rb, v[(ks + 1) & 1]);
+                        if (mt == MT - 1) transform(ra, rb, v[(ks + 1) & 1], mk);
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
                             acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
-                        load_w(mt, it.cb, nx.cb, g + 1);
+                        load_w(mt, wb_it, wb_nx, g + 1);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -417,6 +434,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             if (sink == 123.456f) p.out[tid] = sink;
             if (!have_next) break;
             it = nx;
+            wb_it = wb_nx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cm[c] = cmn[c];
             continue;
         }
         const int tile = tid & 31;                     // reader role: 2x2 tile (tile-row, tile-col) ...
@@ -540,7 +560,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         ++dbg_item;
 #endif
         if (!have_next) break;
-        it = nx;                                   // goff / cm already describe nx
+        it = nx;                                   // goff already describes nx
+        wb_it = wb_nx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cm[c] = cmn[c];
     }
 }
 

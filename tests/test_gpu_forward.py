@@ -55,7 +55,11 @@ def test_net_forward_golden(golden, dim, H, W):
 
 @pytest.mark.parametrize("dim,B,H,W", [(160, 1, 5, 7), (160, 3, 8, 32), (160, 2, 9, 33), (160, 1, 48, 64),
                                        (32, 2, 17, 100), (16, 1, 33, 31), (160, 2, 94, 126),
-                                       (48, 2, 19, 35), (64, 1, 13, 66), (80, 2, 14, 40), (96, 1, 20, 33)])
+                                       (48, 2, 19, 35), (64, 1, 13, 66), (80, 2, 14, 40), (96, 1, 20, 33),
+                                       # several work items per workgroup whose tiles sit in DIFFERENT tile columns, one of
+                                       # them cut by the right image edge (W = 70 -> 3 tile columns): strided and
+                                       # tile-major item orders of the persistent Winograd kernel
+                                       (160, 16, 36, 70), (160, 16, 48, 70)])
 def test_net_forward_vs_oracle_edges(dim, B, H, W):
     """Ragged / tiny / tile-boundary sizes against the oracle; host-t and device-t paths agree."""
     net = _net(dim)
