@@ -18,7 +18,7 @@ INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libsinddm_hip.so")
 STAMP = LIB + ".sha256"
 SOURCES = ["sinddm_fwd.hip", "sinddm_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
 def _hipcc() -> str:

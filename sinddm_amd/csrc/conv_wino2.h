@@ -38,6 +38,8 @@ namespace sinddm {
 #endif
 // Compile-time timing ablations (-DW2_ABL=bits; results are WRONG, never ship):
 //   1 no raw-tile DMA   2 weights loaded once   4 no LDS reads   8 no epilogue   16 no input-transform VALU
+//   32 raw patches read from the exchange area (LDS the DMA never writes)   64 no chunk barrier   128 chunk barrier
+//   without its waitcnt
 #ifndef W2_ABL
 #define W2_ABL 0
 #endif
@@ -63,7 +65,10 @@ struct Wino2Item {          // one unit of work: a 4x32 pixel tile x one block o
     int b, y0, x0, cb;
 };
 
-template <int MT, int ACT>
+// EDGE = 1 when W % 4 != 0: a 16-byte group of the halo tile can then straddle the right image edge, and the columns
+// past it (the next row's first pixels) are zeroed when the patch is transformed -- 8 v_cndmask per k-step that images
+// with W % 4 == 0 (every group is entirely inside or entirely outside a row: hardware zero fill) do not pay.
+template <int MT, int ACT, int MTP, int EDGE>
 __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
     constexpr int NT = 2;
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     // byte offset of (item block cb, chunk 0, this wave's frequency row, k-step 0, m-tile 0) in the packed image -- the
     // one integer division of the weight addressing, once per item instead of once per load
     auto wbase = [&](int cb) -> int {
-        const int mg = cb * MT;                                    // first global m-tile of the item (MT divides p.mtp)
-        const int pcb = mg / p.mtp, pmt = mg - pcb * p.mtp;
-        return (pcb * nch * 4 + wi) * (4096 * p.mtp) + pmt * 1024;
+        const int mg = cb * MT;                                    // first global m-tile of the item (MT divides MTP)
+        const int pcb = mg / MTP, pmt = mg - pcb * MTP;
+        return (pcb * nch * 4 + wi) * (4096 * MTP) + pmt * 1024;
     };
     f32x4 a[MT];                                                   // A operands of the current k-step
     // g = k-step index inside the item; g == nks_total means "k-step 0 of the next item" (output-channel block ncb):
@@ -175,11 +180,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         if ((W2_ABL & 2) && g > 0) return;
         const bool wrap = g >= nks_total;
         const int gg = wrap ? 0 : g;
-        // the packed image is blocked by p.mtp m-tiles per output-channel block; an item covers MT of them (MT == p.mtp
+        // the packed image is blocked by MTP m-tiles per output-channel block; an item covers MT of them (MT == MTP
         // for the big launches, MT = 1 when a launch has too few tiles to fill the chip with whole blocks)
         // (`cb` / `ncb` arrive already split into packed block and first packed m-tile: wbase())
         const int wb = wrap ? ncb : cb;
-        const int so = wb + (gg >> 2) * (4 * 4096) * p.mtp + (gg & 3) * (1024 * p.mtp) + mt * 1024;
+        const int so = wb + (gg >> 2) * (4 * 4096 * MTP) + (gg & 3) * (1024 * MTP) + mt * 1024;
         a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
     };
     // Barriers are written in assembly: hipcc puts a full `s_waitcnt vmcnt(0)` in front of every s_barrier on gfx9,
@@ -189,6 +194,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     //   weight loads of the k-step before the barrier and memory operations complete in order, so vmcnt(MT) covers it;
     //   (b) this wave's LDS reads of the current chunk done: lgkmcnt(0).
     auto chunk_barrier = [&]() {
+        if (W2_ABL & 64) return;
+        if (W2_ABL & 128) { asm volatile("s_barrier" ::: "memory"); return; }
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT) : "memory");
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             // columns right of the image edge hold the next row's pixels (the 16-byte groups run past it): zero padding
             float r0 = fmaf(sgn, rb[nt][0], ra[nt][0]), r1 = fmaf(sgn, rb[nt][1], ra[nt][1]);
             float r2 = fmaf(sgn, rb[nt][2], ra[nt][2]), r3 = fmaf(sgn, rb[nt][3], ra[nt][3]);
-            r0 = cm[0] ? r0 : 0.f; r1 = cm[1] ? r1 : 0.f; r2 = cm[2] ? r2 : 0.f; r3 = cm[3] ? r3 : 0.f;
+            if (EDGE) { r0 = cm[0] ? r0 : 0.f; r1 = cm[1] ? r1 : 0.f; r2 = cm[2] ? r2 : 0.f; r3 = cm[3] ? r3 : 0.f; }
             v[nt][0] = r0 - r2;      // B columns: 0: c0 - c2   1: c1 + c2   2: c2 - c1   3: c1 - c3
             v[nt][1] = r1 + r2;
             v[nt][2] = r2 - r1;
@@ -226,7 +233,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     auto read_piece = [&](const float* base, f32x4 (&ra)[NT], f32x4 (&rb)[NT], int q) {
         const int row = q & 1, nt = (q >> 1) & 1, half = q >> 2;
         if (W2_ABL & 4) { (row ? rb : ra)[nt][half * 2] = (float)q; (row ? rb : ra)[nt][half * 2 + 1] = (float)lane; return; }
-        const float* src = base + (row ? ob : oa) + nt * 2 * W2_RS + half * 2;
+        // `base` already includes this lane's row-a offset (one address computation per k-step); row b, the second
+        // tile-row and the second half are compile-time offsets that fit the ds_read2 offset fields
+        const float* src = ((W2_ABL & 32) ? sX + ((base - smem) & 4095) : base) + (row ? ob - oa : 0) + nt * 2 * W2_RS + half * 2;
         (row ? rb : ra)[nt][half * 2] = src[0];
         (row ? rb : ra)[nt][half * 2 + 1] = src[1];
     };
@@ -242,12 +251,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 break;
             case 1:
                 tr_[3] = fmaf(sgn, rb[nt][3], ra[nt][3]);
-                tr_[0] = cm[0] ? tr_[0] : 0.f;
-                tr_[1] = cm[1] ? tr_[1] : 0.f;
+                if (EDGE) { tr_[0] = cm[0] ? tr_[0] : 0.f; tr_[1] = cm[1] ? tr_[1] : 0.f; }
                 break;
             case 2:
-                tr_[2] = cm[2] ? tr_[2] : 0.f;
-                tr_[3] = cm[3] ? tr_[3] : 0.f;
+                if (EDGE) { tr_[2] = cm[2] ? tr_[2] : 0.f; tr_[3] = cm[3] ? tr_[3] : 0.f; }
                 v[nt][0] = tr_[0] - tr_[2];
                 break;
             default:
@@ -367,6 +374,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     //   m-tile 2: after each of its 8 MFMAs three VALU of the next k-step's input transform
                     //   every m-tile: after its MFMAs the refill of its A registers; in k-step 0 also one channel of the
                     //   next chunk's LDS-DMA (m-tiles 1..4: its ~25 SALU of descriptor arithmetic ride along)
+#ifdef W2_PT_MT
+                    unsigned long long pt[4];
+#endif
 #ifdef W2_KT_KS
                     unsigned long long kt[MT + 1];
                     if (ks == W2_KT_KS) kt[0] = __builtin_amdgcn_s_memtime();
@@ -377,7 +387,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                         for (int q = 0; q < 8; ++q) {
                             acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
-                            if (mt == 0) read_piece(rsrc_, ra, rb, q);
+#ifdef W2_PT_MT
+                            if (ks == W2_KT_KS && mt == W2_PT_MT && (q & 1) == 1) { pt[q >> 1] = __builtin_amdgcn_s_memtime(); }
+#endif
+                            if (mt == 0) read_piece(rsrc_ + oa, ra, rb, q);
                             if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q, mk);
                             if (mt == 0 || mt == 2) __builtin_amdgcn_sched_barrier(0);
                         }
@@ -386,6 +399,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                         // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Spread out on purpose: a wave
                         // BLOCKS at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy --
                         // four of them issued back to back cost ~2000 cycles without a single MFMA.
+                        // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
+                        // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Never back to back: a wave BLOCKS
+                        // at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy -- four of them
+                        // in a row cost ~2000 cycles without a single MFMA.  (Where exactly they sit inside k-steps 0/1
+                        // measured +-0.3 %.)
                         if (ks == 0 && mt >= 1) issue1(dsrc, dch, dval, nxt, mt - 1);
                         if (ks == 0 && mt == MT - 1) {
 #pragma unroll
@@ -400,6 +418,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     if (ks == W2_KT_KS && dbg && c == 2) {
 #pragma unroll
                         for (int i = 0; i <= MT; ++i) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 20 + i) * 4 + wi] = kt[i];
+#ifdef W2_PT_MT
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 30 + i) * 4 + wi] = pt[i];
+#endif
                     }
 #endif
                 } else {
@@ -567,18 +589,24 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     }
 }
 
-template <int MT>
-inline void conv_wino2_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
+template <int MT, int MTP, int EDGE>
+inline void conv_wino2_launch_e(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
 #ifdef W2_ONE_WG
     constexpr size_t lds = 100 * 1024;                       // (experiment) only one workgroup fits a CU
 #else
     constexpr size_t lds = W2_LDS_FLOATS * sizeof(float);
 #endif
     switch (a.act & 0xff) {
-        case 1: hipLaunchKernelGGL((conv_wino2_kernel<MT, 1>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
-        case 2: hipLaunchKernelGGL((conv_wino2_kernel<MT, 2>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
-        default: hipLaunchKernelGGL((conv_wino2_kernel<MT, 0>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx);
+        case 1: hipLaunchKernelGGL((conv_wino2_kernel<MT, 1, MTP, EDGE>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
+        case 2: hipLaunchKernelGGL((conv_wino2_kernel<MT, 2, MTP, EDGE>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx); break;
+        default: hipLaunchKernelGGL((conv_wino2_kernel<MT, 0, MTP, EDGE>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx);
     }
+}
+
+template <int MT, int MTP>
+inline void conv_wino2_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
+    if (a.W % 4 == 0) conv_wino2_launch_e<MT, MTP, 0>(a, grid, ipx, wpx, st);
+    else conv_wino2_launch_e<MT, MTP, 1>(a, grid, ipx, wpx, st);
 }
 
 inline int wino2_cu_count() {
@@ -625,10 +653,12 @@ inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     if (wpx < 1) wpx = 1;
     if (wpx > ipx) wpx = ipx;
     const unsigned grid = (unsigned)(wpx * 8);
-    switch (mt) {
-        case 5: conv_wino2_launch_t<5>(a, grid, ipx, wpx, st); break;
-        case 2: conv_wino2_launch_t<2>(a, grid, ipx, wpx, st); break;
-        case 1: conv_wino2_launch_t<1>(a, grid, ipx, wpx, st); break;
+    switch (mt * 8 + a.mtp) {
+        case 5 * 8 + 5: conv_wino2_launch_t<5, 5>(a, grid, ipx, wpx, st); break;
+        case 2 * 8 + 2: conv_wino2_launch_t<2, 2>(a, grid, ipx, wpx, st); break;
+        case 1 * 8 + 1: conv_wino2_launch_t<1, 1>(a, grid, ipx, wpx, st); break;
+        case 1 * 8 + 2: conv_wino2_launch_t<1, 2>(a, grid, ipx, wpx, st); break;
+        case 1 * 8 + 5: conv_wino2_launch_t<1, 5>(a, grid, ipx, wpx, st); break;
         default: return SINDDM_E_BADSHAPE;
     }
     if (rec) {

@@ -34,6 +34,10 @@ try:
             for g in range(5):
                 print("    group", g, [int(v) for v in d_[g]])
             print("    k-step total", [int(v) for v in (kt[5] - kt[0])])
+            pt = a[wg, it, 30:34]
+            if pt.max() > 0:
+                print("    piece stamps (after MFMA 1,3,5,7 of the probed group) relative to k-step start:",
+                      [[int(pt[i][w] - kt[0][w]) for w in range(4)] for i in range(4)])
     sys.stdout.flush()
     os._exit(0)
 finally:
