@@ -43,9 +43,21 @@ namespace sinddm {
 #ifndef W2_ABL
 #define W2_ABL 0
 #endif
+#ifndef W2_STAGE
+#define W2_STAGE 1           // raw tiles of the big launches through registers (0: LDS-DMA, as the small launches do)
+#endif
 #ifdef W2_TIMING
 // s_memtime stamps of workgroups 8 and 9 (debug builds only; tools/w2_timing.py): [wg][item][slot][wave]
 __device__ unsigned long long g_w2_dbg[2 * 4 * 40 * 4];
+#endif
+#ifdef W2_PHASE
+// per workgroup HW_ID | XCC_ID << 32, then (epilogue start, end) of its first 9 items (tools/w2_phase.py)
+__device__ unsigned long long g_w2_phase[1024 * 20];
+// per workgroup and wave: 16 stamps inside the epilogue of item 3 (tools/w2_phase.py seg)
+__device__ unsigned long long g_w2_seg[1024 * 4 * 16];
+#define W2_SEG(slot) do { if (seg) g_w2_seg[(blockIdx.x * 4 + wi) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W2_SEG(slot) do {} while (0)
 #endif
 constexpr int W2_THREADS = 256;
 constexpr int W2_TW = 32, W2_TH = 4;           // pixel tile
@@ -160,6 +172,26 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue1(ib, c, valid, buf, g);
     };
+    // The same transfer through registers (big launches): the CU's LDS-DMA path moves ~10 B/clk, so the 16 KB raw
+    // tile of a chunk keeps the vector-memory pipe of the CU busy for ~60 % of a chunk when both workgroups stream --
+    // every other memory instruction (weights, epilogue loads and stores) queues behind it.  An ordinary 16-byte load
+    // + ds_write_b128 a k-step later moves the same bytes at the pipe's full rate; two staging slots (8 VGPRs).
+    f32x4 stg[2];
+    // Scalar instructions are the expensive ones here: next to a wave that streams MFMAs, a SALU / LDS / VMEM / s_waitcnt
+    // instruction issues once per 16 cycles (VALU: every 2-3; tools/ubench/valu_next_to_mfma.hip), so the address
+    // arithmetic of the streams is incremental -- one descriptor per chunk (the wave's 4 channel planes of the chunk,
+    // the plane picked by the instruction's scalar offset), one scalar byte offset per k-step for the weights.
+    const unsigned HW4 = (unsigned)HW * 4u;
+    auto plane_ptr = [&](int ib) { return p.in + ((size_t)ib * p.Cin + wi * 4) * HW; };   // (sample, channel 4 wi)
+    __amdgpu_buffer_rsrc_t rs_st;                   // planes of the chunk being staged (Cin % 4 == 0: all four or none)
+    auto stage_load = [&](int slot, int g) {
+        if (W2_ABL & 1) return;
+        stg[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (int)goff, g * (int)HW4, 0));
+    };
+    auto stage_store = [&](int slot, float* buf, int g) {
+        if (W2_ABL & 1) return;
+        *reinterpret_cast<f32x4*>(buf + (wi * 4 + g) * W2_PS + lane * 4) = stg[slot];
+    };
 
     // ---- weights: register image [coblk][chunk][i][ks][mt][lane][j], 16-byte buffer loads ----
     const __amdgpu_buffer_rsrc_t rsw =
@@ -196,6 +228,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     auto chunk_barrier = [&]() {
         if (W2_ABL & 64) return;
         if (W2_ABL & 128) { asm volatile("s_barrier" ::: "memory"); return; }
+        if (W2_STAGE && MT >= 3) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; }
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT) : "memory");
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -294,6 +327,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) load_w(mt, wb_it, wb_it, 0);
     __syncthreads();
+    int wcur = wb_it;                              // weights of (item, chunk, this wave's frequency row, k-step 0, m-tile 0)
+    const float* sstage = plane_ptr(it.b) + (size_t)16 * HW;   // planes of the chunk to stage next (chunk 1 of the item)
     int nb = 0;                                    // raw buffer holding the current chunk (runs across items)
     float v[2][NT][4];                             // B operands, double buffered by k-step parity (runs across items)
     {
@@ -312,6 +347,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         const bool have_next = decode(l, nx);
         if (!have_next) nx = it;
         const int wb_nx = wbase(nx.cb);
+        const float* base_nx = plane_ptr(nx.b);
 #ifdef W2_TIMING
         const bool dbg = (blockIdx.x == 8 || blockIdx.x == 8 + 8 * 32) && dbg_item < 4 && lane == 0;
         if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 39) * 4 + wi] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
@@ -337,7 +373,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         for (int c = 0; c < nch; ++c) {
             const float* cur = smem + nb * W2_BUF;
             float* nxt = smem + (nb ^ 1) * W2_BUF;
-            const bool last = c + 1 == nch;
+            // (opaque: the optimizer must not peel or unswitch the chunk loop on it -- two copies of the body do not fit
+            // the register file)
+            const bool last = __builtin_amdgcn_readfirstlane(c + 1 == nch) != 0;
 #ifdef W2_TIMING
             if (dbg && c < 12) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 3 * c + 0) * 4 + wi] = __builtin_amdgcn_s_memtime();
 #endif
@@ -346,6 +384,15 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             const int dch = last ? 0 : c + 1;
             const bool dval = !last || have_next;
             if (MT < 3) issue(dsrc, dch, dval, nxt);
+            // byte offsets of the weights of k-steps 1..3 of this chunk and of k-step 0 of the next one (next chunk, or
+            // the next item's first)
+            constexpr int W_KS = 1024 * MTP, W_CH = 4 * 4096 * MTP;
+            const int w_k[4] = {wcur + W_KS, wcur + 2 * W_KS, wcur + 3 * W_KS, last ? wb_nx : wcur + W_CH};
+            if constexpr (MT >= 3 && W2_STAGE) {
+                if (last) sstage = base_nx;
+                const bool live = dval && dch * 16 + wi * 4 < p.Cin;
+                rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sstage), 0, live ? 4 * (int)HW4 : 0, 0x00020000);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int g = c * 4 + ks;
@@ -394,7 +441,12 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                             if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q, mk);
                             if (mt == 0 || mt == 2) __builtin_amdgcn_sched_barrier(0);
                         }
+#if W2_STAGE
+                        if (!((W2_ABL & 2) && g + 1 > 0))
+                            a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + mt * 1024, w_k[ks], 0));
+#else
                         load_w(mt, wb_it, wb_nx, g + 1);
+#endif
                         // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
                         // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Spread out on purpose: a wave
                         // BLOCKS at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy --
@@ -404,11 +456,23 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                         // at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy -- four of them
                         // in a row cost ~2000 cycles without a single MFMA.  (Where exactly they sit inside k-steps 0/1
                         // measured +-0.3 %.)
+#if W2_STAGE
+                        //   k-step 0: load ch0 (m-tile 0), ch1 (m-tile 2)      k-step 1: write ch0 + load ch2, write ch1 + load ch3
+                        //   k-step 2: write ch2, ch3 -- all in LDS before the chunk barrier in front of k-step 3
+                        if (mt == 0 || mt == 2) {
+                            const int sl = mt >> 1;
+                            if (ks == 1) stage_store(sl, nxt, sl);
+                            if (ks == 2) stage_store(sl, nxt, 2 + sl);
+                            if (ks == 0) stage_load(sl, sl);
+                            if (ks == 1) stage_load(sl, 2 + sl);
+                        }
+#else
                         if (ks == 0 && mt >= 1) issue1(dsrc, dch, dval, nxt, mt - 1);
                         if (ks == 0 && mt == MT - 1) {
 #pragma unroll
                             for (int gch = MT - 1; gch < 4; ++gch) issue1(dsrc, dch, dval, nxt, gch);
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #ifdef W2_KT_KS
                         if (ks == W2_KT_KS) { kt[mt + 1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
@@ -439,11 +503,21 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 }
             }
             nb ^= 1;
+            wcur = w_k[3];
+            sstage += (size_t)16 * HW;
         }
 
         // ---- output transform + epilogue: column half in registers, row half through LDS, 32 channels per pass ----
 #ifdef W2_TIMING
         if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 36) * 4 + wi] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef W2_PHASE
+        const bool ph = wi == 0 && lane == 0 && p.Cin == 160 && p.Cout == 160 && (l - 1) < 9 && blockIdx.x < 1024;
+        if (ph) {
+            if (l == 1) g_w2_phase[blockIdx.x * 20] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4) |
+                                                        ((unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 20) << 32);
+            g_w2_phase[blockIdx.x * 20 + 2 * (l - 1) + 1] = __builtin_amdgcn_s_memtime();
+        }
 #endif
         if (W2_ABL & 8) {
             float sink = 0.f;                                   // keep every accumulator chain alive
@@ -461,6 +535,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             for (int c = 0; c < 4; ++c) cm[c] = cmn[c];
             continue;
         }
+#ifdef W2_PHASE
+        const bool seg = lane == 0 && p.Cin == 160 && p.Cout == 160 && l == 4 && blockIdx.x < 1024;
+#endif
+        W2_SEG(0);
         const int tile = tid & 31;                     // reader role: 2x2 tile (tile-row, tile-col) ...
         const int tr = tile >> 4, tc = tile & 15;
         const int cg = tid >> 5;                       // ... and channels cg + 8k of a pass
@@ -482,25 +560,36 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         const __amdgpu_buffer_rsrc_t rs_pre = rsrc_of(ACT == 1 ? p.out_pre : nullptr);
         const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
-        const bool pix_ok = y < H && x < W;
-        const bool row1 = y + 1 < H;
+        const bool pix_ok = (y < H) & (x < W);
+        const bool okpp[2] = {pix_ok, bool(pix_ok & (y + 1 < H))};
+        const int cl_lim = p.Cout - it.cb * (MT * 16) - cg;        // channel (m0, k) of this lane exists iff 16 m0 + 8 k < cl_lim
         const unsigned pix_o = ((unsigned)(it.cb * (MT * 16) + cg) * (unsigned)HW + (unsigned)(y * W + x)) * 4u;
+        // channel k of pass m0 exists in the item's block for every lane, or for none (cg < 8): known at compile time
+        auto in_block = [](int m0, int k) { return m0 * 16 + 8 * k + 8 <= MT * 16; };
         // byte offset of (channel k of pass m0, row pp) or OOB
         auto off_of = [&](int m0, int k, int pp) -> unsigned {
-            const int cl = cg + 8 * k;
-            const bool ok = pix_ok && (pp == 0 || row1) && (m0 * 16 + cl < MT * 16) &&
-                            (it.cb * (MT * 16) + m0 * 16 + cl < p.Cout);
-            return ok ? pix_o + (unsigned)(m0 * 16 + 8 * k) * plane_b + (unsigned)(pp * W) * 4u : OOB;
+            const bool ok = okpp[pp] & (m0 * 16 + 8 * k < cl_lim);
+            unsigned o = ok ? pix_o + (unsigned)(m0 * 16 + 8 * k) * plane_b + (unsigned)(pp * W) * 4u : OOB;
+            // opaque to the optimizer: it would otherwise turn "access at (ok ? o : OOB)" back into an exec-masked branch
+            // around the access, and the control-flow merges bring full vmcnt(0) drains (= waits for every store)
+            asm volatile("" : "+v"(o));
+            return o;
         };
         auto ld2 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o) -> f32x2 {
             return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)o, 0, 0));
         };
         // an 8-byte store covers pixels (x, x+1); in the last odd column only pixel x exists: 4-byte store instead
-        const bool edge_tile = it.x0 + W2_TW > W;                   // (wave-uniform) the tile reaches the right image edge
+        // (only when W is odd -- EDGE builds; issued unconditionally there, with an out-of-range offset where unused)
         auto st2 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o, f32x2 vv) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, vv), r, (int)(x1ok ? o : OOB), 0, 0);
-            if (edge_tile)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[0]), r, (int)(x1ok ? OOB : o), 0, 0);
+            if (W2_ABL & 512) { if (vv[0] == 123.4f) p.out[tid] = vv[1]; return; }
+            if constexpr (EDGE) {
+                unsigned o2 = x1ok ? o : OOB, o1 = x1ok ? OOB : o;
+                asm volatile("" : "+v"(o2), "+v"(o1));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, vv), r, (int)o2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[0]), r, (int)o1, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, vv), r, (int)o, 0, 0);
+            }
         };
         // residual / pre-activation / bias operands of a pass: requested one pass AHEAD, before the stores of the pass in
         // between -- memory operations complete in order, so a wait for them never waits for a store
@@ -509,6 +598,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         auto prefetch = [&](int m0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (!in_block(m0, k)) continue;
+                if (W2_ABL & 256) { bs_v[k] = 0.f; rs_v[k][0] = rs_v[k][1] = f32x2{0.f, 0.f}; ax_v[k][0] = ax_v[k][1] = f32x2{1.f, 1.f}; continue; }
                 bs_v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     rs_bias, (it.cb * (MT * 16) + m0 * 16 + cg + 8 * k) * 4, 0, 0));
 #pragma unroll
@@ -537,10 +628,13 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 }
             }
             if (m0 == 0) prefetch(0);                              // (its accumulators are dead: registers are free)
+            W2_SEG(1 + (m0 / 2) * 5);
             lds_barrier();
+            W2_SEG(2 + (m0 / 2) * 5);
             f32x2 yv[4][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (!in_block(m0, k)) continue;
                 const int cl = cg + 8 * k;                         // channel of the pass (0..31)
                 f32x2 t[4];
 #pragma unroll
@@ -548,10 +642,13 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 yv[k][0] = t[0] + t[1] + t[2];                     // Y[pp][q] = sum_i A^T[pp][i] t[i][q]
                 yv[k][1] = t[1] - t[2] - t[3];
             }
+            W2_SEG(3 + (m0 / 2) * 5);
             lds_barrier();                                         // the exchange area is free for the next pass
+            W2_SEG(4 + (m0 / 2) * 5);
             f32x2 val[4][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (!in_block(m0, k)) continue;
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     f32x2 w_ = yv[k][pp] + bs_v[k];
@@ -569,6 +666,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             if (m0 + 2 < MT) prefetch(m0 + 2);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (!in_block(m0, k)) continue;
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const unsigned o = off_of(m0, k, pp);
@@ -576,10 +674,14 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     st2(rs_out, o, val[k][pp]);
                 }
             }
+            W2_SEG(5 + (m0 / 2) * 5);
         }
 #ifdef W2_TIMING
         if (dbg) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 37) * 4 + wi] = __builtin_amdgcn_s_memtime();
         ++dbg_item;
+#endif
+#ifdef W2_PHASE
+        if (ph) g_w2_phase[blockIdx.x * 20 + 2 * (l - 1) + 2] = __builtin_amdgcn_s_memtime();
 #endif
         if (!have_next) break;
         it = nx;                                   // goff already describes nx

@@ -841,6 +841,14 @@ int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_
     return 0;
 }
 
+#ifdef W2_PHASE
+int sinddm_debug_w2_seg(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_seg), sizeof(unsigned long long) * n);
+}
+int sinddm_debug_w2_phase(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_phase), sizeof(unsigned long long) * n);
+}
+#endif
 #ifdef W2_TIMING
 int sinddm_debug_w2_timing(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_dbg), sizeof(unsigned long long) * n);
