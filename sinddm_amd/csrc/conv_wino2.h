@@ -19,9 +19,16 @@
 //   * weights (U, pre-transformed by the pack kernel) are laid out [co-block][16-ch chunk][i][k-step][mt][lane][j]:
 //     ONE 16-byte buffer load per (k-step, mt) brings a lane its four A operands; every load is issued right after
 //     the last MFMA that reads the registers it overwrites, i.e. two k-steps (80 MFMAs) ahead of its use.
-//   * raw input halo tile (16 channels x 6 x 34, plane padded to 256 floats): LDS-DMA, four whole-wave instructions
-//     per channel with per-lane global offsets (hardware bounds check zero-fills halo / missing channels), double
-//     buffered, one 4-wave barrier per 16-channel chunk.
+//   * raw input halo tile (16 channels x 6 x 40, plane padded to 256 floats), double buffered, one 4-wave barrier per
+//     16-channel chunk.  Big launches (MT >= 3) bring it through registers: one 16-byte buffer load per channel with
+//     per-lane global offsets (hardware bounds check zero-fills halo / missing channels) and a ds_write_b128 a k-step
+//     later; the small-launch kernels (MT < 3) use LDS-DMA (no registers to spare for latency there).
+//   * the instruction mix is the design constraint (tools/ubench/valu_next_to_mfma.hip): while the other wave of the
+//     SIMD streams MFMAs, a wave issues VALU every 2-3 cycles but SALU / LDS / VMEM / s_waitcnt only once per 16
+//     cycles.  Address arithmetic of both streams is therefore incremental (one descriptor per chunk, one scalar
+//     offset per k-step: 17 SALU per 160 MFMAs), validity tests are VALU selects on offsets (out-of-range offset =
+//     hardware drop / zero fill) instead of exec-mask branches, and the pieces are pinned between MFMAs with
+//     sched_barrier so a lone wave never meets a block of non-MFMA work.
 // Same ConvArgs / epilogue contract as conv_mfma.h (bias, GELU / GELU'(aux) *, identity residual, pre-activation
 // save); 1x1 residual projections are not fused (the caller passes their result as `resid`).
 #pragma once
@@ -30,12 +37,6 @@
 
 namespace sinddm {
 
-#ifndef W2_DESYNC
-#define W2_DESYNC 1
-#endif
-#ifndef W2_PIN
-#define W2_PIN 1
-#endif
 // Compile-time timing ablations (-DW2_ABL=bits; results are WRONG, never ship):
 //   1 no raw-tile DMA   2 weights loaded once   4 no LDS reads   8 no epilogue   16 no input-transform VALU
 //   32 raw patches read from the exchange area (LDS the DMA never writes)   64 no chunk barrier   128 chunk barrier
@@ -300,25 +301,6 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     Wino2Item it;
     int l = 0;
     if (!decode(l, it)) return;
-#if W2_DESYNC
-    {
-        // The two workgroups of a CU start together and their items take equal time, so left alone they stay in phase
-        // (both in the epilogue at once = the matrix pipe idles exactly as in the 16-wave kernel).  The hardware wave slot
-        // (HW_REG_HW_ID[3:0]) tells the first-dispatched workgroup of a SIMD from the second.
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
-        if (W2_DESYNC & 1) {
-            // static priority: the slot-1 workgroup owns the matrix pipe whenever it has MFMAs to issue; the other one
-            // fills every gap it leaves (its epilogues, barrier ramps, prologues) and gets the pipe alone meanwhile
-            if (slot) __builtin_amdgcn_s_setprio(1);
-        }
-        if (W2_DESYNC & 2) {
-            // start the slot-1 workgroup about half a work item late
-            if (slot) {
-                for (int i = 0; i < nch; ++i) __builtin_amdgcn_s_sleep(127);
-            }
-        }
-    }
-#endif
     make_goff(it);
 #pragma unroll
     for (int c = 0; c < 4; ++c) cm[c] = cmn[c];

@@ -37,9 +37,10 @@ struct TrainBufs {
     float* wscr;    // [dim][9][dim] staging slab of the 3x3 weight-gradient kernel
 };
 
+struct ChainStep;   // sampler-run extras (sinddm_fwd.hip)
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
-                     hipStream_t st, const TrainBufs* tb);
+                     hipStream_t st, const TrainBufs* tb, const ChainStep* cs = nullptr);
 
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
                   const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st);

@@ -164,6 +164,7 @@ struct CondArgs {
     const float* params;
     const long long* t_dev;
     int t_host;
+    int t_step;          // t of block b = t_host + b * t_step when t_dev is null (a run of sampler steps in one launch)
     float scale;
     float* out;          // [B][cond_stride]
     int cond_stride;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const float* P = a.params;
-    const float tval = a.t_dev ? (float)a.t_dev[b] : (float)a.t_host;
+    const float tval = a.t_dev ? (float)a.t_dev[b] : (float)(a.t_host + b * a.t_step);
     if (tid < 32) {
         // f_i = exp(i * -(ln 1e4 / 15)): torch.exp(arange(16) * -emb) on CPU returns the correctly
         // rounded fp32 exp of the fp32 argument; a double-precision exp rounded to fp32 reproduces it.
@@ -545,6 +546,42 @@ __global__ __launch_bounds__(256) void reverse_step_rng_kernel(const float* __re
     }
 }
 
+// final 1x1 conv (-> eps) + reverse step + in-kernel noise in one pass (sampler runs; H*W % 4 == 0 so that a thread's
+// four pixels are one quad of the flat [B][3][H][W] index the generator is keyed on -- same numbers as the two-kernel
+// path): eps never goes to memory.
+__global__ __launch_bounds__(256) void final_conv_reverse_step_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias,
+                                                                      const float* __restrict__ xt,
+                                                                      const float* __restrict__ xtil, float* __restrict__ out,
+                                                                      sinddm_step_coefs k, int C, int HW,
+                                                                      unsigned long long seed, unsigned long long step) {
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const float* src = a + (size_t)b * C * HW + p;
+    f32x4 e[3] = {{bias[0], bias[0], bias[0], bias[0]}, {bias[1], bias[1], bias[1], bias[1]}, {bias[2], bias[2], bias[2], bias[2]}};
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)c * HW);
+        e[0] += w[c] * v;
+        e[1] += w[C + c] * v;
+        e[2] += w[2 * C + c] * v;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long i0 = ((long long)b * 3 + c) * HW + p;
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k.sigma != 0.0f) philox_normal4(seed, step, (unsigned long long)(i0 >> 2), z);
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xt + i0);
+        f32x4 xb{0.f, 0.f, 0.f, 0.f};
+        if (k.mode != 0) xb = *reinterpret_cast<const f32x4*>(xtil + i0);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = reverse_step_mean(k, x[j], e[c][j], xb[j], 1.f, 0.f, false) + k.sigma * z[j];
+        *reinterpret_cast<f32x4*>(out + i0) = o;
+    }
+}
+
 // standalone N(0,1) fill from the same generator (tests; initial / re-noise draws of the sampler)
 __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed,
                                                             unsigned long long step) {
@@ -590,15 +627,31 @@ struct FwdBuffers {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// conditioning rows: one per sample (sinddm_net_forward) or one per sampler step of a run (sinddm_sample_chain: every
+// sample of the batch shares the step's t, so a whole run of steps is embedded by ONE cond_kernel launch)
+constexpr int CHAIN_COND_ROWS = 1024;
+static size_t cond_region_bytes(const NetPlan& P, int B) {
+    const int rows = B > CHAIN_COND_ROWS ? B : CHAIN_COND_ROWS;
+    return align_up((size_t)rows * P.cond_stride * sizeof(float), 256);
+}
 static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
     const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
-    const size_t cond = align_up((size_t)B * P.cond_stride * sizeof(float), 256);
-    return cond + 4 * act;
+    return cond_region_bytes(P, B) + 4 * act;
 }
+
+// sampler-run extras of net_forward_impl: the step's conditioning row (already computed, shared by the batch) and the
+// fused tail (final conv + reverse step)
+struct ChainStep {
+    const float* cond_row;
+    const float* x_tilde;
+    float* x_next;
+    sinddm_step_coefs coefs;
+    unsigned long long seed, stream_id;
+};
 
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
-                     hipStream_t st, const TrainBufs* tb) {
+                     hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
     FwdBuffers fb{};
     if (tb) {
         fb.cond = tb->cond;
@@ -606,10 +659,12 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         if (ws_bytes < fwd_workspace_bytes(P, B, H, W)) return SINDDM_E_WORKSPACE;
         char* base = static_cast<char*>(ws);
         fb.cond = reinterpret_cast<float*>(base);
-        base += align_up((size_t)B * P.cond_stride * sizeof(float), 256);
+        base += cond_region_bytes(P, B);
         const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
         for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
     }
+    int cond_stride = P.cond_stride;
+    if (cs) { fb.cond = const_cast<float*>(cs->cond_row); cond_stride = 0; }
 
     CondArgs ca{};
     ca.params = params; ca.t_dev = reinterpret_cast<const long long*>(t_dev); ca.t_host = t_host; ca.scale = scale;
@@ -622,8 +677,10 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
     }
     ca.cond_vec = tb ? tb->cvec : nullptr; ca.hidden = tb ? tb->hpre : nullptr;
     ca.emb_out = tb ? tb->emb : nullptr; ca.mvec_out = tb ? tb->mvec : nullptr;
-    hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(128), 0, st, ca);
-    SINDDM_LAUNCH_CHECK();
+    if (!cs) {
+        hipLaunchKernelGGL(cond_kernel, dim3(B), dim3(128), 0, st, ca);
+        SINDDM_LAUNCH_CHECK();
+    }
 
     const float* cur = x;
     int freeb[4] = {0, 1, 2, 3};
@@ -637,7 +694,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         float* hbuf = tb ? tb->h[l] : fb.buf[sel[0]];
         float* gbuf = tb ? tb->g[l] : fb.buf[sel[1]];
         float* obuf = tb ? tb->o[l] : fb.buf[sel[2]];
-        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, P.cond_stride, nullptr, 0,
+        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, cond_stride, nullptr, 0,
                                hbuf, B, b.cin, H, W, st);
         if (rc) return rc;
         const bool wino = wino_enabled();
@@ -691,6 +748,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         curb = sel[2];
     }
     const int HW = H * W;
+    if (cs && cs->x_next && HW % 4 == 0) {
+        hipLaunchKernelGGL(final_conv_reverse_step_kernel, dim3((HW / 4 + 255) / 256, B), dim3(256), 0, st, cur,
+                           params + P.fin_w, params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, HW, cs->seed,
+                           cs->stream_id);
+        SINDDM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(final_conv1x1_kernel, dim3(((HW + 3) / 4 + 255) / 256, B), dim3(256), 0, st, cur, params + P.fin_w,
                        params + P.fin_b, out, P.half, HW);
     SINDDM_LAUNCH_CHECK();
@@ -810,16 +874,46 @@ int sinddm_sample_chain(const float* params, const float* packed, float* x, floa
     const long long n = (long long)B * CHANNELS * H * W;
     long long bx = ((n + 3) / 4 + 255) / 256;
     if (bx > 8192) bx = 8192;
+    if (ws_bytes < fwd_workspace_bytes(p, B, H, W)) return SINDDM_E_WORKSPACE;
+    float* cond_tab = static_cast<float*>(ws);                 // the conditioning region: one row per step of a run
+    const bool fuse_tail = (H * W) % 4 == 0;
     float* cur = x;
     float* nxt = x_alt;
-    for (int i = 0; i < n_steps; ++i) {
-        if (coefs[i].mode != 0 && !x_tilde) return SINDDM_E_BADARG;
-        int rc = net_forward_impl(p, params, packed, cur, nullptr, t_list[i], scale, eps, B, H, W, ws, ws_bytes, st, nullptr);
-        if (rc) return rc;
-        hipLaunchKernelGGL(reverse_step_rng_kernel, dim3((unsigned)bx), dim3(256), 0, st, cur, eps, x_tilde, nxt, coefs[i], n,
-                           (unsigned long long)seed, (unsigned long long)(stream_id0 + (uint64_t)i));
+    for (int i0 = 0; i0 < n_steps;) {
+        // a run: up to CHAIN_COND_ROWS steps whose t is an arithmetic progression (the sampler's always is)
+        int len = 1, dt = 0;
+        if (i0 + 1 < n_steps) {
+            dt = t_list[i0 + 1] - t_list[i0];
+            len = 2;
+            while (i0 + len < n_steps && len < CHAIN_COND_ROWS && t_list[i0 + len] - t_list[i0 + len - 1] == dt) ++len;
+        }
+        CondArgs ca{};
+        ca.params = params; ca.t_dev = nullptr; ca.t_host = t_list[i0]; ca.t_step = dt; ca.scale = scale;
+        ca.out = cond_tab; ca.cond_stride = p.cond_stride;
+        ca.tm0_w = p.tm0_w; ca.tm0_b = p.tm0_b; ca.tm2_w = p.tm2_w; ca.tm2_b = p.tm2_b;
+        for (int l = 0; l < 4; ++l) {
+            ca.mlp_w[l] = p.blk[l].mlp_w; ca.mlp_b[l] = p.blk[l].mlp_b;
+            ca.tr_w[l] = p.blk[l].tr_w; ca.tr_b[l] = p.blk[l].tr_b;
+            ca.cin[l] = p.blk[l].cin; ca.coff[l] = p.blk[l].cond_off;
+        }
+        hipLaunchKernelGGL(cond_kernel, dim3(len), dim3(128), 0, st, ca);
         SINDDM_LAUNCH_CHECK();
-        float* t_ = cur; cur = nxt; nxt = t_;
+        for (int i = i0; i < i0 + len; ++i) {
+            if (coefs[i].mode != 0 && !x_tilde) return SINDDM_E_BADARG;
+            ChainStep cs{};
+            cs.cond_row = cond_tab + (size_t)(i - i0) * p.cond_stride;
+            cs.x_tilde = x_tilde; cs.x_next = fuse_tail ? nxt : nullptr; cs.coefs = coefs[i];
+            cs.seed = (unsigned long long)seed; cs.stream_id = (unsigned long long)(stream_id0 + (uint64_t)i);
+            int rc = net_forward_impl(p, params, packed, cur, nullptr, t_list[i], scale, eps, B, H, W, ws, ws_bytes, st, nullptr, &cs);
+            if (rc) return rc;
+            if (!fuse_tail) {
+                hipLaunchKernelGGL(reverse_step_rng_kernel, dim3((unsigned)bx), dim3(256), 0, st, cur, eps, x_tilde, nxt, coefs[i],
+                                   n, (unsigned long long)seed, (unsigned long long)(stream_id0 + (uint64_t)i));
+                SINDDM_LAUNCH_CHECK();
+            }
+            float* t_ = cur; cur = nxt; nxt = t_;
+        }
+        i0 += len;
     }
     if (result_in_alt) *result_in_alt = (cur == x_alt) ? 1 : 0;
     return 0;

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
-rm -f gpurun_out/ab.log
-python -m pytest tests/test_gpu_forward.py tests/test_gpu_parity_band.py tests/test_gpu_train.py -m gpu -x -q 2>&1 | tail -3
-bash tools/ab2.sh "n2 n4" 2 "C2 C3"
-python tools/w2_phase.py P 2>&1 | grep -A20 "epilogue segments"
+python -m pytest tests/test_gpu_sampler_fast.py tests/test_gpu_forward.py tests/test_gpu_parity_band.py tests/test_gpu_e2e.py -m gpu -x -q 2>&1 | tail -3
+python tools/scale_times.py C2 16 2>&1 | tail -6
+python tools/scale_times.py C2 1 2>&1 | tail -6
