@@ -181,7 +181,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
     traffic = _traffic(cfg_name)
     roofline = {
         "bound": "mfma",
-        "kernel": "conv_wino_kernel<5,3,*> (Winograd F(2x2,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32; 7 launches per step)",
+        "kernel": "conv_wino2_kernel<5,*,5,*> (Winograd F(2x2,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32; 7 launches per step)",
         "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic,
