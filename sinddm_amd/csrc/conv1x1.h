@@ -131,6 +131,229 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Second generation for the 80-channel-block shapes (C_out = 80 or 160): the 80 -> 160 projection is MFMA-bound at
+// fp32 (26.7 FLOP per byte against a machine balance of 19.6), so what matters is that every byte is read once and the
+// matrix pipe never waits for a barrier:
+//   * persistent 4-wave workgroups; the whole [C_in][C_out] weight matrix sits in LDS (staged once per workgroup in
+//     MFMA A-operand order [k-step][m-tile][lane]: one conflict-free ds_read_b32 per (k-step, m-tile));
+//   * a wave owns 64 consecutive pixels for ALL output channels (MTT = C_out / 16 <= 10 m-tiles x 4 n-tiles = 160
+//     accumulator registers): the input is read exactly once, straight from global memory into the B registers (one
+//     16-byte load per k-step and lane, 4-8 k-steps in flight) -- no LDS round trip, no barrier in the pixel loop;
+//   * same epilogue contract as above (bias, GELU / GELU'(aux) *, residual, 16-byte stores).
+// -------------------------------------------------------------------------------------------------------------------
+
+#ifndef C1B_ABL
+#define C1B_ABL 0        // timing ablations (wrong results): 1 no B loads in the loop, 2 no A reads in the loop, 4 no epilogue memory ops
+#endif
+template <int MTT, int ACT, int TAIL, int RES = 1>   // TAIL = 1 when H*W % 4 != 0: a lane's 4 pixels can straddle the end of a plane; RES = 0: no residual operand
+__global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, int tiles_per_img, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // [nks][MTT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int HW = p.H * p.W;
+    const int Cin = p.Cin2;
+    const int nks = (Cin + 3) >> 2;
+    constexpr int CO_LDS = ConvCfg<5, 4>::CO_LDS;                      // 80: packed image [coblk][chunk8][ci8][CO_LDS]
+    constexpr unsigned OOB = 0x40000000u;
+    constexpr int C1B_PF = 4;                                          // k-steps of B operands in flight per wave
+    const int nks_pad = (nks + C1B_PF - 1) / C1B_PF * C1B_PF;          // the k-loop is branch-free: padded steps multiply zeros
+
+    // ---- weights -> LDS, once: element (ci, co) lands at [(ci >> 2) * MTT + (co >> 4)][(ci & 3) * 16 + (co & 15)].
+    // The packed image is read linearly (coalesced), ten independent loads per thread in flight; the zero padding of
+    // the k-steps beyond C_in is written first.
+    for (int e = tid; e < nks_pad * MTT * 64; e += C1_THREADS) smem[e] = 0.f;
+    __syncthreads();
+    {
+        const int per_cb = p.nch1 * KC * CO_LDS;                        // floats per output-channel block
+        const int total = (MTT / 5) * per_cb;
+        for (int e0 = 0; e0 < total; e0 += C1_THREADS * 10) {
+            float v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int e = e0 + u * C1_THREADS + tid;
+                v[u] = e < total ? p.w1[e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int e = e0 + u * C1_THREADS + tid;
+                const int cb = e >= per_cb ? 1 : 0;
+                const int r = e - cb * per_cb;
+                const int ci = r / CO_LDS, col = r - ci * CO_LDS;
+                const int co = cb * 80 + col;
+                if (e < total && ci < Cin) smem[((ci >> 2) * MTT + (co >> 4)) * 64 + (ci & 3) * 16 + (co & 15)] = v[u];
+            }
+        }
+    }
+    // bias -> LDS too: the epilogue needs 4 * MTT per-lane values per tile, and a global load each would be 4 * MTT
+    // serial memory round trips per tile
+    float* sbias = smem + nks_pad * MTT * 64;
+    for (int e = tid; e < MTT * 16; e += C1_THREADS) sbias[e] = p.bias ? p.bias[e] : 0.f;
+    __syncthreads();
+
+    // The B-operand stream runs ACROSS tiles: the last C1B_PF k-steps of a tile load the first k-steps of the next one,
+    // BEFORE the epilogue's stores -- memory operations complete in order, so a load issued after 40 stores would wait
+    // for every one of them (measured: 20 % of the kernel).
+    struct TileCtx {
+        __amdgpu_buffer_rsrc_t rs;
+        unsigned pxo;
+    };
+    auto make_ctx = [&](int tile) {
+        TileCtx c;
+        const bool live = tile < ntiles;
+        const int b = live ? tile / tiles_per_img : 0;
+        const int p0 = (tile - b * tiles_per_img) * C1_PIX;
+        const int px = p0 + wave * 64 + l16 * 4;
+        c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 + (size_t)b * Cin * HW), 0, live ? Cin * HW * 4 : 0,
+                                                 0x00020000);
+        c.pxo = px < HW ? (unsigned)px * 4u : OOB;
+        return c;
+    };
+    // B operand of k-step ks: channel 4 ks + kq, the lane's 4 consecutive pixels (MFMA column l16 of n-tile nt = pixel + nt)
+    auto load_b = [&](const TileCtx& c, int ks) -> f32x4 {
+        const int ch = 4 * ks + kq;
+        unsigned o = ch < Cin ? c.pxo + (unsigned)(ch * HW) * 4u : OOB;
+        asm volatile("" : "+v"(o));
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, (int)o, 0, 0));
+    };
+    f32x4 bq[C1B_PF];
+    TileCtx ctx = make_ctx(blockIdx.x);
+#pragma unroll
+    for (int i = 0; i < C1B_PF; ++i) bq[i] = load_b(ctx, i);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img;
+        const int p0 = (tile - b * tiles_per_img) * C1_PIX;
+        const int px0 = p0 + wave * 64 + l16 * 4;                       // this lane's 4 consecutive pixels
+        const TileCtx nctx = make_ctx(tile + gridDim.x);
+        f32x4 acc[MTT][4];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // A operands ping-pong between two register sets: the reads of k-step ks+1 are ISSUED before the MFMAs of k-step
+        // ks (pinned by the sched_barrier: left alone the compiler sinks them to the end of the k-step to save ten
+        // registers, and every k-step then starts with an exposed LDS round trip)
+        float aa[2][MTT];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) aa[0][mt] = smem[mt * 64 + lane];
+        for (int k0 = 0; k0 < nks_pad; k0 += C1B_PF) {
+#pragma unroll
+            for (int i = 0; i < C1B_PF; ++i) {
+                const int ks = k0 + i;
+                const f32x4 bv = bq[i];
+                if (!(C1B_ABL & 1)) {
+                    const bool wrap = k0 + C1B_PF >= nks_pad;           // (uniform) last group: the next tile's first k-steps
+                    TileCtx lc;
+                    lc.rs = wrap ? nctx.rs : ctx.rs;
+                    lc.pxo = wrap ? nctx.pxo : ctx.pxo;
+                    bq[i] = load_b(lc, wrap ? i : ks + C1B_PF);
+                }
+                const int kn = ks + 1 < nks_pad ? ks + 1 : 0;           // (the wrap-around read is never used)
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt) aa[(i + 1) & 1][mt] = (C1B_ABL & 2) ? aa[i & 1][mt] + 1.f : smem[(kn * MTT + mt) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MTT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[i & 1][mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue: lane holds rows 4 kq + r of every m-tile for its 4 pixels.  Without a plane tail every access is
+        // a 16-byte BUFFER access on the sample's descriptor (lanes past the image carry an out-of-range offset; a null
+        // residual is an empty descriptor): no branches, so the loads of an m-tile are in flight together and no
+        // control-flow merge drains the stores.
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const size_t samp = (size_t)b * p.Cout * HW;
+        const unsigned samp_b = (unsigned)(p.Cout * HW) * 4u;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out + samp, 0, samp_b, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.resid ? p.resid + samp : p.zero), 0, p.resid ? samp_b : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(ACT == 2 ? p.aux + samp : p.zero), 0, ACT == 2 ? samp_b : 0u, 0x00020000);
+        // residual / pre-activation operands of an m-tile are requested BEFORE the stores of the previous one: memory
+        // operations complete in order, so a load issued after a store waits for that store's round trip
+        unsigned off[2][4];
+        f32x4 rv[2][4], uv[2][4];
+        auto fetch = [&](int mt, int slot) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned o = px0 < HW ? (unsigned)((mt * 16 + kq * 4 + r) * HW + px0) * 4u : OOB;
+                asm volatile("" : "+v"(o));
+                off[slot][r] = o;
+                if (C1B_ABL & 4) { rv[slot][r] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if constexpr (RES) rv[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)o, 0, 0));
+                if constexpr (ACT == 2) uv[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (int)o, 0, 0));
+            }
+        };
+        if constexpr (!TAIL) fetch(0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
+            if constexpr (!TAIL) {
+                if (mt + 1 < MTT) fetch(mt + 1, (mt + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f32x4 v{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                    v += bias4[r];
+                    if constexpr (ACT == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                    } else if constexpr (ACT == 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(uv[mt & 1][r][j]);
+                    }
+                    if constexpr (RES) v += rv[mt & 1][r];
+                    if (C1B_ABL & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.4f) p.out[tid] = v[1]; continue; }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off[mt & 1][r], 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = mt * 16 + kq * 4 + r;                 // (< C_out = MTT * 16 by construction)
+                    const size_t o = samp + (size_t)co * HW + px0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (px0 + j < HW) {
+                            float w = acc[mt][j][r] + bias4[r];
+                            if constexpr (ACT == 1) w = gelu_erf(w);
+                            else if constexpr (ACT == 2) w *= gelu_erf_grad(p.aux[o + j]);
+                            if (p.resid) w += p.resid[o + j];
+                            p.out[o + j] = w;
+                        }
+                    }
+                }
+            }
+        }
+        ctx = nctx;
+    }
+}
+
+template <int MTT>
+inline void conv1x1_all_launch(const ConvArgs& a, unsigned grid, size_t lds, int tpi, int ntiles, hipStream_t st) {
+    // (H*W % 4 != 0 stays on the first-generation kernel: the TAIL = 1 epilogue is scalar)
+#define C1B_GO(ACT, RES) hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), dim3(grid), dim3(C1_THREADS), lds, st, a, tpi, ntiles)
+    const int res = a.resid != nullptr;
+    switch ((a.act & 0xff) * 2 + res) {
+        case 0: C1B_GO(0, 0); break;
+        case 1: C1B_GO(0, 1); break;
+        case 2: C1B_GO(1, 0); break;
+        case 3: C1B_GO(1, 1); break;
+        case 4: C1B_GO(2, 0); break;
+        default: C1B_GO(2, 1);
+    }
+#undef C1B_GO
+}
+
+#ifndef SINDDM_CONV1X1_V2
+#define SINDDM_CONV1X1_V2 1
+#endif
+
 inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
     ConvProfiler& prof = conv_profiler();
     const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
@@ -145,6 +368,15 @@ inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
     const int HW = a.H * a.W;
     const int tpi = (HW + C1_PIX - 1) / C1_PIX;
     const dim3 grid((unsigned)(a.B * tpi), (unsigned)a.coblks);
+    const int mtt = mt * a.coblks;
+    const size_t lds2 = ((size_t)((a.Cin2 + 15) / 16 * 4) * mtt * 64 + mtt * 16) * sizeof(float);   // k-steps padded to a multiple of 4, + bias
+    if (SINDDM_CONV1X1_V2 && mt == 5 && (mtt == 5 || mtt == 10) && a.Cout == mtt * 16 && lds2 <= 64 * 1024 && HW % 4 == 0) {
+        const int ntiles = a.B * tpi;
+        const int cus = 256;
+        const unsigned g2 = (unsigned)(ntiles < 2 * cus ? ntiles : 2 * cus);
+        if (mtt == 10) conv1x1_all_launch<10>(a, g2, lds2, tpi, ntiles, st);
+        else conv1x1_all_launch<5>(a, g2, lds2, tpi, ntiles, st);
+    } else
     switch (mt) {
         case 5: { constexpr size_t lds = 2 * (C1_KC * ConvCfg<5, 4>::CO_LDS + C1_KC * C1_PS) * sizeof(float);
                   hipLaunchKernelGGL(conv1x1_mfma_kernel<5>, grid, dim3(C1_THREADS), lds, st, a, tpi); break; }
