@@ -289,12 +289,15 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
                 if constexpr (ACT == 2) uv[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (int)o, 0, 0));
             }
         };
-        if constexpr (!TAIL) fetch(0, 0);
+        // TAIL builds (H*W % 4 != 0): only the last tile of an image has lanes whose 4 pixels straddle the end of a plane;
+        // it takes the scalar path (a wave-uniform branch), every other tile the 16-byte one
+        const bool tail_tile = TAIL && p0 + C1_PIX > HW;
+        if (!tail_tile) {
+            fetch(0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
-            if constexpr (!TAIL) {
+            for (int mt = 0; mt < MTT; ++mt) {
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
                 if (mt + 1 < MTT) fetch(mt + 1, (mt + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -312,7 +315,12 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
                     if (C1B_ABL & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.4f) p.out[tid] = v[1]; continue; }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off[mt & 1][r], 0, 0);
                 }
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MTT; ++mt) {
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = mt * 16 + kq * 4 + r;                 // (< C_out = MTT * 16 by construction)
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
                             float w = acc[mt][j][r] + bias4[r];
                             if constexpr (ACT == 1) w = gelu_erf(w);
                             else if constexpr (ACT == 2) w *= gelu_erf_grad(p.aux[o + j]);
-                            if (p.resid) w += p.resid[o + j];
+                            if constexpr (RES) w += p.resid[o + j];
                             p.out[o + j] = w;
                         }
                     }
@@ -336,7 +344,8 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
 
 template <int MTT>
 inline void conv1x1_all_launch(const ConvArgs& a, unsigned grid, size_t lds, int tpi, int ntiles, hipStream_t st) {
-    // (H*W % 4 != 0 stays on the first-generation kernel: the TAIL = 1 epilogue is scalar)
+    // (H*W % 4 != 0 stays on the first-generation kernel: the TAIL = 1 instantiation measured no faster -- 80+ spilled
+    // registers around its scalar tail path)
 #define C1B_GO(ACT, RES) hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), dim3(grid), dim3(C1_THREADS), lds, st, a, tpi, ntiles)
     const int res = a.resid != nullptr;
     switch ((a.act & 0xff) * 2 + res) {
