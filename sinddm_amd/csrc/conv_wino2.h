@@ -78,7 +78,7 @@ struct Wino2Item {          // one unit of work: a 4x32 pixel tile x one block o
     int b, y0, x0, cb;
 };
 
-// EDGE = 1 when W % 4 != 0: a 16-byte group of the halo tile can then straddle the right image edge, and the columns
+// EDGE >= 1 when W % 4 != 0 (2 when W is odd: the last column is then stored with 4-byte stores): a 16-byte group of the halo tile can then straddle the right image edge, and the columns
 // past it (the next row's first pixels) are zeroed when the patch is transformed -- 8 v_cndmask per k-step that images
 // with W % 4 == 0 (every group is entirely inside or entirely outside a row: hardware zero fill) do not pay.
 template <int MT, int ACT, int MTP, int EDGE>
@@ -561,10 +561,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)o, 0, 0));
         };
         // an 8-byte store covers pixels (x, x+1); in the last odd column only pixel x exists: 4-byte store instead
-        // (only when W is odd -- EDGE builds; issued unconditionally there, with an out-of-range offset where unused)
+        // (only when W is odd -- EDGE = 2 builds; issued unconditionally there, with an out-of-range offset where unused)
         auto st2 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o, f32x2 vv) {
             if (W2_ABL & 512) { if (vv[0] == 123.4f) p.out[tid] = vv[1]; return; }
-            if constexpr (EDGE) {
+            if constexpr (EDGE == 2) {
                 unsigned o2 = x1ok ? o : OOB, o1 = x1ok ? OOB : o;
                 asm volatile("" : "+v"(o2), "+v"(o1));
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, vv), r, (int)o2, 0, 0);
@@ -690,7 +690,8 @@ inline void conv_wino2_launch_e(const ConvArgs& a, unsigned grid, int ipx, int w
 template <int MT, int MTP>
 inline void conv_wino2_launch_t(const ConvArgs& a, unsigned grid, int ipx, int wpx, hipStream_t st) {
     if (a.W % 4 == 0) conv_wino2_launch_e<MT, MTP, 0>(a, grid, ipx, wpx, st);
-    else conv_wino2_launch_e<MT, MTP, 1>(a, grid, ipx, wpx, st);
+    else if (a.W % 2 == 0) conv_wino2_launch_e<MT, MTP, 1>(a, grid, ipx, wpx, st);     // column masks only
+    else conv_wino2_launch_e<MT, MTP, 2>(a, grid, ipx, wpx, st);                         // + 4-byte stores of the last odd column
 }
 
 inline int wino2_cu_count() {
