@@ -255,26 +255,39 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
                                                        int cond_stride, const float* __restrict__ addt, int flip,
                                                        float* __restrict__ out, int C, int H, int W, int groupsX) {
-    __shared__ float tile[DW_NX][DW_HR * DW_RS];
+    __shared__ __attribute__((aligned(16))) float tile[DW_NX][DW_HR * DW_RS];
     const int c = blockIdx.y, b = blockIdx.z;
     const int ty = blockIdx.x / groupsX, gxi = blockIdx.x - ty * groupsX;
     const int y0 = ty * DW_TH, xg0 = gxi * (DW_NX * DW_TW);
     const size_t plane = ((size_t)b * C + c) * H * W;
     const float* src = x + plane;
-    // stage all DW_NX halo tiles: every load is issued before the first LDS write (the loads are independent;
-    // a rolled loop would wait for each one in turn and make the kernel latency-bound)
-    constexpr int DW_LD = (DW_HR * DW_RS + 255) / 256;
-    float stg[DW_NX][DW_LD];
+    // stage all DW_NX halo tiles: every load is issued before the first LDS write (the loads are independent; a rolled
+    // loop would wait for each one in turn and make the kernel latency-bound).  16-byte groups: a halo row is 33 groups
+    // of 4 floats (columns x0-2 .. x0+129), 660 groups per tile, 3 per thread; the loads are BUFFER loads on the plane
+    // (rows outside the image get an out-of-range offset: hardware zero fill), columns past the row end are masked per
+    // element (they would read the next row).
+    constexpr int DW_GR = DW_RS / 4;                       // groups per halo row (33)
+    constexpr int DW_NG = DW_HR * DW_GR;                   // groups per tile (660)
+    constexpr int DW_LD = (DW_NG + 255) / 256;             // per thread (3)
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, H * W * 4, 0x00020000);
+    f32x4 stg[DW_NX][DW_LD];
 #pragma unroll
     for (int t = 0; t < DW_NX; ++t) {
         const int x0 = xg0 + t * DW_TW;
 #pragma unroll
         for (int k = 0; k < DW_LD; ++k) {
             const int i = threadIdx.x + k * 256;
-            const int r = i / DW_RS, cc = i - r * DW_RS;
-            const int gy = y0 + r - 2, gx = x0 + cc - 2;
-            const bool ok = i < DW_HR * DW_RS && x0 < W && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            stg[t][k] = ok ? src[(size_t)gy * W + gx] : 0.0f;
+            const int r = i / DW_GR, g = i - r * DW_GR;
+            const int gy = y0 + r - 2, gx = x0 + 4 * g - 2;
+            const bool rowok = i < DW_NG && x0 < W && gy >= 0 && gy < H;
+            // the leftmost group of an image (gx = -2) is loaded from column 0 and shifted by two elements
+            const bool left = gx < 0;
+            const int off = rowok ? (gy * W + (left ? 0 : gx)) * 4 : 0x40000000;     // (out of range -> zero fill)
+            const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
+            f32x4 v = left ? f32x4{0.f, 0.f, q[0], q[1]} : q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (rowok && gx + e < W) ? v[e] : 0.0f;
+            stg[t][k] = v;
         }
     }
 #pragma unroll
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < DW_LD; ++k) {
             const int i = threadIdx.x + k * 256;
-            if (i < DW_HR * DW_RS) tile[t][i] = stg[t][k];
+            if (i < DW_NG) *reinterpret_cast<f32x4*>(&tile[t][i * 4]) = stg[t][k];
         }
     float wk[25];
 #pragma unroll
