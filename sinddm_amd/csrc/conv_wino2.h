@@ -44,6 +44,9 @@ namespace sinddm {
 #ifndef W2_ABL
 #define W2_ABL 0
 #endif
+#ifndef W2_ADB
+#define W2_ADB 0             // (experiment) double-buffered A registers: all weight loads at the head of the k-step
+#endif
 #ifndef W2_WMERGE
 #define W2_WMERGE 0          // (experiment) 2 + 1 merged waits per k-step instead of 5 + 3: measured -1.4 % (waits come earlier)
 #endif
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         const int pcb = mg / MTP, pmt = mg - pcb * MTP;
         return (pcb * nch * 4 + wi) * (4096 * MTP) + pmt * 1024;
     };
-    f32x4 a[MT];                                                   // A operands of the current k-step
+    f32x4 a[2][MT];                                                // A operands of the current k-step ([1]: W2_ADB double buffer)
     // g = k-step index inside the item; g == nks_total means "k-step 0 of the next item" (output-channel block ncb):
     // the weight stream, like the raw-tile stream, runs across items without a branch inside a k-step -- a chunk stays
     // one basic block, which the register allocator needs to accumulate in place
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         // (`cb` / `ncb` arrive already split into packed block and first packed m-tile: wbase())
         const int wb = wrap ? ncb : cb;
         const int so = wb + (gg >> 2) * (4 * 4096 * MTP) + (gg & 3) * (1024 * MTP) + mt * 1024;
-        a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
+        a[0][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
     };
     // Barriers are written in assembly: hipcc puts a full `s_waitcnt vmcnt(0)` in front of every s_barrier on gfx9,
     // which would drain the weight loads issued a moment ago (main loop) and expose the completion latency of every
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
         if (W2_ABL & 64) return;
         if (W2_ABL & 128) { asm volatile("s_barrier" ::: "memory"); return; }
         if (W2_STAGE && MT >= 3) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; }
+        if (W2_ADB && MT >= 3) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(3 * MT) : "memory"); return; }
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(MT) : "memory");
     };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -263,41 +267,6 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             v[nt][1] = r1 + r2;
             v[nt][2] = r2 - r1;
             v[nt][3] = r1 - r3;
-        }
-    };
-
-    // The same two steps cut into 8 pieces each, one per MFMA of an m-tile group (fine-grained schedule below)
-    auto read_piece = [&](const float* base, f32x4 (&ra)[NT], f32x4 (&rb)[NT], int q) {
-        const int row = q & 1, nt = (q >> 1) & 1, half = q >> 2;
-        if (W2_ABL & 4) { (row ? rb : ra)[nt][half * 2] = (float)q; (row ? rb : ra)[nt][half * 2 + 1] = (float)lane; return; }
-        // `base` already includes this lane's row-a offset (one address computation per k-step); row b, the second
-        // tile-row and the second half are compile-time offsets that fit the ds_read2 offset fields
-        const float* src = ((W2_ABL & 32) ? sX + ((base - smem) & 4095) : base) + (row ? ob - oa : 0) + nt * 2 * W2_RS + half * 2;
-        (row ? rb : ra)[nt][half * 2] = src[0];
-        (row ? rb : ra)[nt][half * 2 + 1] = src[1];
-    };
-    float tr_[4];                                   // row-combined patch of the tile-row being transformed
-    auto transform_piece = [&](const f32x4 (&ra)[NT], const f32x4 (&rb)[NT], float (&v)[NT][4], int q, const bool (&cm)[4]) {
-        const int nt = q >> 2;
-        if (W2_ABL & 16) { if ((q & 3) == 0) { v[nt][0] = ra[nt][0]; v[nt][1] = rb[nt][1]; v[nt][2] = ra[nt][2]; v[nt][3] = rb[nt][3]; } return; }
-        switch (q & 3) {
-            case 0:
-                tr_[0] = fmaf(sgn, rb[nt][0], ra[nt][0]);
-                tr_[1] = fmaf(sgn, rb[nt][1], ra[nt][1]);
-                tr_[2] = fmaf(sgn, rb[nt][2], ra[nt][2]);
-                break;
-            case 1:
-                tr_[3] = fmaf(sgn, rb[nt][3], ra[nt][3]);
-                if (EDGE) { tr_[0] = cm[0] ? tr_[0] : 0.f; tr_[1] = cm[1] ? tr_[1] : 0.f; }
-                break;
-            case 2:
-                if (EDGE) { tr_[2] = cm[2] ? tr_[2] : 0.f; tr_[3] = cm[3] ? tr_[3] : 0.f; }
-                v[nt][0] = tr_[0] - tr_[2];
-                break;
-            default:
-                v[nt][1] = tr_[1] + tr_[2];
-                v[nt][2] = tr_[2] - tr_[1];
-                v[nt][3] = tr_[1] - tr_[3];
         }
     };
 
@@ -399,90 +368,42 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) mk[cc] = (ks == 3 && last) ? cmn[cc] : cm[cc];
                 if constexpr (MT >= 3) {
-                    // Fine-grained, pinned order (a sched_barrier after every piece): one MFMA occupies the matrix pipe
-                    // for 32 cycles, and whatever this wave issues in that shadow is free -- whatever it issues in a
-                    // block in FRONT of its MFMAs is a bubble nobody fills when the wave is alone on its SIMD.
-                    //   m-tile 0: after each of its 8 MFMAs one LDS read (2 floats) of the next k-step's raw patches
-                    //   m-tile 2: after each of its 8 MFMAs three VALU of the next k-step's input transform
-                    //   every m-tile: after its MFMAs the refill of its A registers; in k-step 0 also one channel of the
-                    //   next chunk's LDS-DMA (m-tiles 1..4: its ~25 SALU of descriptor arithmetic ride along)
-#ifdef W2_PT_MT
-                    unsigned long long pt[4];
+                    // Everything that is not an MFMA sits at the head of the k-step, then 8 * MT MFMAs run back to back (only
+                    // the A refills between the m-tiles): the partner wave's burst covers this wave's head.  (A fine-grained
+                    // version -- one LDS read / three VALU pinned behind every MFMA of m-tiles 0 and 2 -- measured 1 % slower
+                    // at two waves per SIMD and no faster for a lone wave.)
+#if W2_STAGE
+                    if (ks == 1) { stage_store(0, nxt, 0); stage_store(1, nxt, 1); }
+                    if (ks == 2) { stage_store(0, nxt, 2); stage_store(1, nxt, 3); }
+#else
+                    if (ks == 0) issue(dsrc, dch, dval, nxt);
 #endif
-#ifdef W2_KT_KS
-                    unsigned long long kt[MT + 1];
-                    if (ks == W2_KT_KS) kt[0] = __builtin_amdgcn_s_memtime();
+                    read_raw(rsrc_, ra, rb);
+#if W2_STAGE
+                    if (ks == 0) { stage_load(0, 0); stage_load(1, 1); }
+                    if (ks == 1) { stage_load(0, 2); stage_load(1, 3); }
 #endif
+#if W2_ADB
+                    // all five A refills of the NEXT k-step here, into the other register set: the burst below is pure MFMA
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        a[(ks + 1) & 1][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + mt * 1024, w_k[ks], 0));
+#endif
+                    transform(ra, rb, v[(ks + 1) & 1], mk);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-#if W2_WMERGE
-                        // two vmcnt waits per k-step instead of one per m-tile (a wait is an issue slot of the throttled
-                        // class): the empty asm "uses" A registers of later m-tiles here, so the compiler waits for them
-                        // now; they were requested at least three m-tiles ago
-                        if (MT == 5 && mt == 0) asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]));
-                        if (MT == 5 && mt == 3) asm volatile("" ::"v"(a[3]), "v"(a[4]));
-                        // ... and one lgkmcnt wait for the raw patches (read beside m-tile 0, transformed beside m-tile 2)
-                        if (mt == 2) asm volatile("" ::"v"(ra[0]), "v"(ra[1]), "v"(rb[0]), "v"(rb[1]));
-                        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
+                        for (int q = 0; q < 8; ++q)
+                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[W2_ADB ? (ks & 1) : 0][mt][q & 3], v[ks & 1][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
-#ifdef W2_PT_MT
-                            if (ks == W2_KT_KS && mt == W2_PT_MT && (q & 1) == 1) { pt[q >> 1] = __builtin_amdgcn_s_memtime(); }
-#endif
-                            if (mt == 0) read_piece(rsrc_ + oa, ra, rb, q);
-                            if (mt == 2) transform_piece(ra, rb, v[(ks + 1) & 1], q, mk);
-                            if (mt == 0 || mt == 2) __builtin_amdgcn_sched_barrier(0);
-                        }
-#if W2_STAGE
+#if !W2_ADB
                         if (!((W2_ABL & 2) && g + 1 > 0))
-                            a[mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + mt * 1024, w_k[ks], 0));
-#else
-                        load_w(mt, wb_it, wb_nx, g + 1);
-#endif
-                        // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
-                        // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Spread out on purpose: a wave
-                        // BLOCKS at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy --
-                        // four of them issued back to back cost ~2000 cycles without a single MFMA.
-                        // LDS-DMA of the next chunk's raw tile: one channel after each of m-tiles 1..4 of k-step 0 (its
-                        // ~25 SALU of descriptor arithmetic ride along with the MFMAs).  Never back to back: a wave BLOCKS
-                        // at the issue of an LDS-DMA instruction while the CU's DMA path (~10 B/clk) is busy -- four of them
-                        // in a row cost ~2000 cycles without a single MFMA.  (Where exactly they sit inside k-steps 0/1
-                        // measured +-0.3 %.)
-#if W2_STAGE
-                        //   k-step 0: load ch0 (m-tile 0), ch1 (m-tile 2)      k-step 1: write ch0 + load ch2, write ch1 + load ch3
-                        //   k-step 2: write ch2, ch3 -- all in LDS before the chunk barrier in front of k-step 3
-                        if (mt == 0 || mt == 2) {
-                            const int sl = mt >> 1;
-                            if (ks == 1) stage_store(sl, nxt, sl);
-                            if (ks == 2) stage_store(sl, nxt, 2 + sl);
-                            if (ks == 0) stage_load(sl, sl);
-                            if (ks == 1) stage_load(sl, 2 + sl);
-                        }
-#else
-                        if (ks == 0 && mt >= 1) issue1(dsrc, dch, dval, nxt, mt - 1);
-                        if (ks == 0 && mt == MT - 1) {
-#pragma unroll
-                            for (int gch = MT - 1; gch < 4; ++gch) issue1(dsrc, dch, dval, nxt, gch);
-                        }
-#endif
+                            a[0][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + mt * 1024, w_k[ks], 0));
                         __builtin_amdgcn_sched_barrier(0);
-#ifdef W2_KT_KS
-                        if (ks == W2_KT_KS) { kt[mt + 1] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #endif
                     }
-#ifdef W2_KT_KS
-                    if (ks == W2_KT_KS && dbg && c == 2) {
-#pragma unroll
-                        for (int i = 0; i <= MT; ++i) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 20 + i) * 4 + wi] = kt[i];
-#ifdef W2_PT_MT
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) g_w2_dbg[((dbg_wg * 4 + dbg_item) * 40 + 30 + i) * 4 + wi] = pt[i];
-#endif
-                    }
-#endif
+                    __builtin_amdgcn_sched_barrier(0);
                 } else {
                     read_raw(rsrc_, ra, rb);
 #pragma unroll
@@ -490,7 +411,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                         if (mt == MT - 1) transform(ra, rb, v[(ks + 1) & 1], mk);
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
-                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][q & 3], v[ks & 1][q >> 2][q & 3],
+                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][mt][q & 3], v[ks & 1][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
                         load_w(mt, wb_it, wb_nx, g + 1);
                         __builtin_amdgcn_sched_barrier(0);

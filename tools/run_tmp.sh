@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-rm -f gpurun_out/ab.log
-python -m pytest tests/test_gpu_forward.py tests/test_gpu_parity_band.py -m gpu -x -q 2>&1 | tail -3
-bash tools/ab2.sh "w0 w1" 2 "C2 C3"
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python tools/scale_times.py C2 16 2>&1 | tail -6
