@@ -44,6 +44,9 @@ namespace sinddm {
 #ifndef W2_ABL
 #define W2_ABL 0
 #endif
+#ifndef W2_THEAD
+#define W2_THEAD 0           // (experiment) transform at the head of the k-step that uses it (no LDS wait in a head): +-0
+#endif
 #ifndef W2_ADB
 #define W2_ADB 0             // (experiment) double-buffered A registers: all weight loads at the head of the k-step
 #endif
@@ -285,7 +288,12 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     const float* sstage = plane_ptr(it.b) + (size_t)16 * HW;   // planes of the chunk to stage next (chunk 1 of the item)
     int nb = 0;                                    // raw buffer holding the current chunk (runs across items)
     float v[2][NT][4];                             // B operands, double buffered by k-step parity (runs across items)
-    {
+    // W2_THEAD (big launches): the raw patches of a k-step are read at the head of the PREVIOUS k-step and transformed at
+    // the head of their own -- no LDS round trip in a head, one B-operand set; they stay in registers across the epilogue
+    f32x4 pra[NT], prb[NT];
+    if (W2_THEAD && MT >= 3) {
+        read_raw(smem, pra, prb);
+    } else {
         f32x4 ra[NT], rb[NT];
         read_raw(smem, ra, rb);
         transform(ra, rb, v[0], cm);
@@ -378,7 +386,13 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
 #else
                     if (ks == 0) issue(dsrc, dch, dval, nxt);
 #endif
+#if W2_THEAD
+                    transform(pra, prb, v[0], cm);                   // this k-step's operands (raw data read a k-step ago)
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_raw(rsrc_, pra, prb);                       // the next k-step's raw patches
+#else
                     read_raw(rsrc_, ra, rb);
+#endif
 #if W2_STAGE
                     if (ks == 0) { stage_load(0, 0); stage_load(1, 1); }
                     if (ks == 1) { stage_load(0, 2); stage_load(1, 3); }
@@ -389,13 +403,15 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     for (int mt = 0; mt < MT; ++mt)
                         a[(ks + 1) & 1][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + mt * 1024, w_k[ks], 0));
 #endif
+#if !W2_THEAD
                     transform(ra, rb, v[(ks + 1) & 1], mk);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
-                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[W2_ADB ? (ks & 1) : 0][mt][q & 3], v[ks & 1][q >> 2][q & 3],
+                            acc[mt][q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[W2_ADB ? (ks & 1) : 0][mt][q & 3], v[W2_THEAD ? 0 : (ks & 1)][q >> 2][q & 3],
                                                                                           acc[mt][q >> 2][q & 3], 0, 0, 0);
 #if !W2_ADB
                         if (!((W2_ABL & 2) && g + 1 > 0))
