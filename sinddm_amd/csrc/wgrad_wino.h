@@ -19,6 +19,7 @@
 // frequency (1,1), whose dM is the plain sum of the 2x2 block.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace sinddm {
 
@@ -67,31 +68,6 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
     const int ci0 = cib * WW_CI;
     const int nci = min(WW_CI, p.Cin - ci0);
     const int nnt = (nci + 15) >> 4;                 // 16-channel ci tiles that exist in this slab (wave-uniform)
-
-    // ---- operand recipes of this frequency ----
-    const int fi = xi >> 2, fj = xi & 3;
-    // dM = A dY A^T:  A rows  0: +y0   1: +y0 +y1   2: +y0 -y1   3: -y1   (same for the columns: even / odd pixel).
-    // Only the non-zero terms are read: 1, 2 or 4 of them (2.25 on average over the 16 frequencies).
-    const int nr = (fi == 1 || fi == 2) ? 2 : 1, nc = (fj == 1 || fj == 2) ? 2 : 1;
-    const int arow = fi == 3 ? 1 : 0, acol = fj == 3 ? 1 : 0;              // first (or only) row / half read
-    const float sr0 = fi == 3 ? -1.f : 1.f, sr1 = fi == 2 ? -1.f : 1.f;      // sign of the first / second row term
-    const float sc0 = fj == 3 ? -1.f : 1.f, sc1 = fj == 2 ? -1.f : 1.f;
-    const int aterms = nr * nc;                                              // 1, 2 or 4 (wave-uniform)
-    // V = B^T d B:  rows  0: +d0 -d2   1: +d1 +d2   2: -d1 +d2   3: +d1 -d3   (patch index p = 2*idx + half)
-    const int pa0 = fi == 0 ? 0 : 1, pa1 = fi == 3 ? 3 : 2;
-    const int pb0 = fj == 0 ? 0 : 1, pb1 = fj == 3 ? 3 : 2;
-    const float sa0 = fi == 2 ? -1.f : 1.f, sa1 = (fi == 0 || fi == 3) ? -1.f : 1.f;
-    const float sb0 = fj == 2 ? -1.f : 1.f, sb1 = (fj == 0 || fj == 3) ? -1.f : 1.f;
-    const float b00 = sa0 * sb0, b01 = sa0 * sb1, b10 = sa1 * sb0, b11 = sa1 * sb1;
-    // LDS offsets (floats) of the four terms; tile column c = 4*kstep + kq is added through the lane / immediates
-    const int abase = l16 * WW_PSO + kq + arow * 16 + acol * 8;             // plane = [row][half][idx]
-    // term 0: (arow, acol); term 1: the second half if nc == 2, else the second row; terms 2, 3: second row
-    const int oa0 = abase, oa1 = abase + (nc == 2 ? 8 : 16), oa2 = abase + 16, oa3 = abase + 24;
-    const float as0 = sr0 * sc0, as1 = (nc == 2) ? sr0 * sc1 : sr1 * sc0, as2 = sr1 * sc0, as3 = sr1 * sc1;
-    const int bbase = WW_CO * WW_PSO + l16 * WW_PSI + kq;
-    auto xoff = [&](int pr, int pc) { return pr * WW_XR + (pc & 1) * 9 + (pc >> 1); };
-    const int ob00 = bbase + xoff(pa0, pb0), ob01 = bbase + xoff(pa0, pb1);
-    const int ob10 = bbase + xoff(pa1, pb0), ob11 = bbase + xoff(pa1, pb1);
 
     // ---- LDS-DMA of one pixel tile (buffer bounds check zero-fills everything outside the image / channel range) ----
     // dY: 80 planes of 64 floats, one whole-wave instruction each (5 per wave).  Input: 48 halo planes of 108 floats,
@@ -167,61 +143,96 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
 #pragma unroll
         for (int g = 0; g < 6; ++g) issue_group(ta, smem, g);
     }
-    for (int tile = t_begin; tile < t_end; ++tile, ++it) {
-        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
-        const float* cur = smem + (it & 1) * WW_BUF;
-        float* nxt = smem + ((it + 1) & 1) * WW_BUF;
-        const bool pf = tile + 1 < t_end && !(SINDDM_WW_ABL & 1);
-        TileAddr ta{};
-        if (pf) {
-            ta = tile_addr(nb, nty, ntx);
-            advance();
-        }
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
+    auto run_tiles = [&](auto xi_c) {
+        constexpr int XI = decltype(xi_c)::value;
+        // ---- operand recipes of this frequency: compile-time per wave (the switch below picks the wave's copy of the
+        // loop), so the signs are adds/subs, the 1- and 2-term frequencies skip their zero terms, and the operand reads
+        // of a term pair merge into ds_read2_b32 (constant offset differences): ~13 instead of 23 LDS instructions per
+        // k-step of 15 MFMAs -- the loop is LDS-issue bound
+        constexpr int fi = XI >> 2, fj = XI & 3;
+        // dM = A dY A^T:  A rows  0: +y0   1: +y0 +y1   2: +y0 -y1   3: -y1   (same for the columns: even / odd pixel).
+        // Only the non-zero terms are read: 1, 2 or 4 of them (2.25 on average over the 16 frequencies).
+        constexpr int nr = (fi == 1 || fi == 2) ? 2 : 1, nc = (fj == 1 || fj == 2) ? 2 : 1;
+        constexpr int arow = fi == 3 ? 1 : 0, acol = fj == 3 ? 1 : 0;            // first (or only) row / half read
+        constexpr float sr0 = fi == 3 ? -1.f : 1.f, sr1 = fi == 2 ? -1.f : 1.f;   // sign of the first / second row term
+        constexpr float sc0 = fj == 3 ? -1.f : 1.f, sc1 = fj == 2 ? -1.f : 1.f;
+        constexpr int aterms = nr * nc;                                           // 1, 2 or 4
+        // V = B^T d B:  rows  0: +d0 -d2   1: +d1 +d2   2: -d1 +d2   3: +d1 -d3   (patch index p = 2*idx + half)
+        constexpr int pa0 = fi == 0 ? 0 : 1, pa1 = fi == 3 ? 3 : 2;
+        constexpr int pb0 = fj == 0 ? 0 : 1, pb1 = fj == 3 ? 3 : 2;
+        constexpr float sa0 = fi == 2 ? -1.f : 1.f, sa1 = (fi == 0 || fi == 3) ? -1.f : 1.f;
+        constexpr float sb0 = fj == 2 ? -1.f : 1.f, sb1 = (fj == 0 || fj == 3) ? -1.f : 1.f;
+        constexpr float b00 = sa0 * sb0, b01 = sa0 * sb1, b10 = sa1 * sb0, b11 = sa1 * sb1;
+        // LDS offsets (floats) of the four terms; tile column c = 4*kstep + kq is added through the lane / immediates
+        const int abase = l16 * WW_PSO + kq;                                      // plane = [row][half][idx]
+        constexpr int oa0 = arow * 16 + acol * 8, oa1 = oa0 + (nc == 2 ? 8 : 16), oa2 = oa0 + 16, oa3 = oa0 + 24;
+        constexpr float as0 = sr0 * sc0, as1 = (nc == 2) ? sr0 * sc1 : sr1 * sc0, as2 = sr1 * sc0, as3 = sr1 * sc1;
+        const int bbase = WW_CO * WW_PSO + l16 * WW_PSI + kq;
+        constexpr int ob00 = pa0 * WW_XR + (pb0 & 1) * 9 + (pb0 >> 1), ob01 = pa0 * WW_XR + (pb1 & 1) * 9 + (pb1 >> 1);
+        constexpr int ob10 = pa1 * WW_XR + (pb0 & 1) * 9 + (pb0 >> 1), ob11 = pa1 * WW_XR + (pb1 & 1) * 9 + (pb1 >> 1);
+        for (int tile = t_begin; tile < t_end; ++tile, ++it) {
+            __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+            const float* cur = smem + (it & 1) * WW_BUF;
+            float* nxt = smem + ((it + 1) & 1) * WW_BUF;
+            const bool pf = tile + 1 < t_end && !(SINDDM_WW_ABL & 1);
+            TileAddr ta{};
             if (pf) {
-                issue_group(ta, nxt, j);
-                if (j < 2) issue_group(ta, nxt, j + 4);
+                ta = tile_addr(nb, nty, ntx);
+                advance();
             }
-            float a[5], bv[3];
-            const float* qd = cur + (j >> 1) * 32 + (j & 1) * 4;       // tile row j>>1, tile columns 4*(j&1) + kq
-            if (SINDDM_WW_ABL & 2) {
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * (float)(j + mt);
-            } else if (aterms == 4) {
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
-                    const float* q = qd + mt * 16 * WW_PSO;
-                    a[mt] = as0 * q[oa0] + as1 * q[oa1] + as2 * q[oa2] + as3 * q[oa3];
+    #pragma unroll 1
+            for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
+                if (pf) {
+                    issue_group(ta, nxt, j);
+                    if (j < 2) issue_group(ta, nxt, j + 4);
                 }
-            } else if (aterms == 2) {
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
-                    const float* q = qd + mt * 16 * WW_PSO;
-                    a[mt] = as0 * q[oa0] + as1 * q[oa1];
+                float a[5], bv[3];
+                const float* qd = cur + abase + (j >> 1) * 32 + (j & 1) * 4;   // tile row j>>1, tile columns 4*(j&1) + kq
+                if (SINDDM_WW_ABL & 2) {
+    #pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * (float)(j + mt);
+                } else if constexpr (aterms == 4) {
+    #pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) {
+                        const float* q = qd + mt * 16 * WW_PSO;
+                        a[mt] = as0 * q[oa0] + as1 * q[oa1] + as2 * q[oa2] + as3 * q[oa3];
+                    }
+                } else if constexpr (aterms == 2) {
+    #pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) {
+                        const float* q = qd + mt * 16 * WW_PSO;
+                        a[mt] = as0 * q[oa0] + as1 * q[oa1];
+                    }
+                } else {
+    #pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * qd[mt * 16 * WW_PSO + oa0];
                 }
-            } else {
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) a[mt] = as0 * qd[mt * 16 * WW_PSO + oa0];
-            }
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                const float* qx = cur + nt * 16 * WW_PSI + (j >> 1) * 36 + (j & 1) * 4;
-                bv[nt] = (SINDDM_WW_ABL & 2) ? b00 * (float)(j - nt) : b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
-            }
-            if (dobias) {
-#pragma unroll
-                for (int mt = 0; mt < 5; ++mt) bsum[mt] += a[mt];
-            }
-#pragma unroll
-            for (int nt = 0; nt < 3; ++nt) {
-                if (nt < nnt) {
-#pragma unroll
-                    for (int mt = 0; mt < 5; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    #pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    const float* qx = cur + bbase + nt * 16 * WW_PSI + (j >> 1) * 36 + (j & 1) * 4;
+                    bv[nt] = (SINDDM_WW_ABL & 2) ? b00 * (float)(j - nt) : b00 * qx[ob00] + b01 * qx[ob01] + b10 * qx[ob10] + b11 * qx[ob11];
+                }
+                if (dobias) {
+    #pragma unroll
+                    for (int mt = 0; mt < 5; ++mt) bsum[mt] += a[mt];
+                }
+    #pragma unroll
+                for (int nt = 0; nt < 3; ++nt) {
+                    if (nt < nnt) {
+    #pragma unroll
+                        for (int mt = 0; mt < 5; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
         }
+
+    };
+    switch (xi) {
+#define WW_CASE(n) case n: run_tiles(std::integral_constant<int, n>{}); break;
+        WW_CASE(0) WW_CASE(1) WW_CASE(2) WW_CASE(3) WW_CASE(4) WW_CASE(5) WW_CASE(6) WW_CASE(7)
+        WW_CASE(8) WW_CASE(9) WW_CASE(10) WW_CASE(11) WW_CASE(12) WW_CASE(13) WW_CASE(14) default: run_tiles(std::integral_constant<int, 15>{});
+#undef WW_CASE
     }
 
     // ---- epilogue: dg = G^T dU G per (co, ci), one 16-channel M tile at a time through LDS ----
