@@ -161,13 +161,14 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
     d.img_prev_upsample = x_tilde
     img = d._q_sample_impl(x_tilde, None, total_t, torch.randn_like(x_tilde))
     t_seq = [(total_t - 1 - i) % total_t for i in range(warmup + steps)]
-    for i in range(warmup):
-        img = d._p_sample_host_t(img, t_seq[i], s)
+    # the production sampler path: one library call per run of steps (sinddm_sample_chain: fused final conv + reverse
+    # step with in-kernel noise) -- exactly what sample() / sample_via_scale() execute at this scale
+    if warmup:
+        img = d._run_steps(img, s, t_seq[:warmup])
     ctx.barrier()
     lib.sinddm_prof_begin()
     t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        img = d._p_sample_host_t(img, t_seq[i], s)
+    img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
     ctx.barrier()
     dt = time.perf_counter() - t0
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
