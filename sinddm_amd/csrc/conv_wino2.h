@@ -27,8 +27,10 @@
 //     SIMD streams MFMAs, a wave issues VALU every 2-3 cycles but SALU / LDS / VMEM / s_waitcnt only once per 16
 //     cycles.  Address arithmetic of both streams is therefore incremental (one descriptor per chunk, one scalar
 //     offset per k-step: 17 SALU per 160 MFMAs), validity tests are VALU selects on offsets (out-of-range offset =
-//     hardware drop / zero fill) instead of exec-mask branches, and the pieces are pinned between MFMAs with
-//     sched_barrier so a lone wave never meets a block of non-MFMA work.
+//     hardware drop / zero fill) instead of exec-mask branches.
+//   * burst schedule: all non-MFMA work of a k-step (stage stores, raw-patch reads, stage loads, input transform) sits
+//     at its head, then the 8 * MT MFMAs run back to back with only the A refills between the m-tiles (pinned with
+//     sched_barrier): the two waves of a SIMD alternate bursts and heads.  Anything else inside a burst costs 1-6 %.
 // Same ConvArgs / epilogue contract as conv_mfma.h (bias, GELU / GELU'(aux) *, identity residual, pre-activation
 // save); 1x1 residual projections are not fused (the caller passes their result as `resid`).
 #pragma once
