@@ -28,6 +28,9 @@ namespace sinddm {
 #define SINDDM_WW_ABL 0
 #endif
 
+#ifndef WW_UNROLL
+#define WW_UNROLL 1          // k-step loop of a tile fully unrolled (the compiler overlaps the operand reads of k-step j+1 with the MFMAs of j): -2 % of a training step
+#endif
 constexpr int WW_THREADS = 1024;
 constexpr int WW_CO = 80, WW_CI = 48;
 constexpr int WW_TW = 16, WW_TH = 4;                 // pixel tile = 2 x 8 2x2-tiles (4 k-steps of 4 tile columns)
@@ -180,7 +183,11 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
                 ta = tile_addr(nb, nty, ntx);
                 advance();
             }
-    #pragma unroll 1
+    #if WW_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
             for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
                 if (pf) {
                     issue_group(ta, nxt, j);
