@@ -248,8 +248,15 @@ __global__ __launch_bounds__(128) void cond_kernel(CondArgs a) {
 // kernel is as much VALU- as bandwidth-limited (25 FMA per 8 bytes).  With flip=1 the taps are mirrored (transposed
 // conv = data gradient) and `addt` is added to the result (residual-path gradient).
 // =====================================================================================
-constexpr int DW_TH = 16, DW_TW = 128, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
-constexpr int DW_NX = 2;   // x-tiles per workgroup: all their loads are in flight together (latency-bound otherwise)
+#ifndef DW_RW_
+#define DW_RW_ 4
+#endif
+constexpr int DW_RW = DW_RW_;             // output rows per wave
+constexpr int DW_TH = 4 * DW_RW, DW_TW = 128, DW_RS = DW_TW + 4, DW_HR = DW_TH + 4;
+#ifndef DW_NX_
+#define DW_NX_ 2
+#endif
+constexpr int DW_NX = DW_NX_;   // x-tiles per workgroup: all their loads are in flight together (latency-bound otherwise)
 
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
@@ -307,17 +314,17 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     for (int t = 0; t < DW_NX; ++t) {
         const int x0 = xg0 + t * DW_TW;
         if (x0 >= W) break;
-        f32x2 o[4];
+        f32x2 o[DW_RW];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = f32x2{add, add};
+        for (int r = 0; r < DW_RW; ++r) o[r] = f32x2{add, add};
 #pragma unroll
-        for (int dy = 0; dy < 8; ++dy) {
+        for (int dy = 0; dy < DW_RW + 4; ++dy) {
             f32x2 v[5];
-            const float* row = &tile[t][(wv * 4 + dy) * DW_RS + lane];
+            const float* row = &tile[t][(wv * DW_RW + dy) * DW_RS + lane];
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) v[dx] = f32x2{row[dx], row[dx + 64]};      // columns lane+dx and lane+64+dx
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < DW_RW; ++r) {
                 const int ky = dy - r;
                 if (ky >= 0 && ky < 5) {
 #pragma unroll
@@ -330,8 +337,8 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
             const int gx = x0 + lane + 64 * h;
             if (gx < W) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gy = y0 + wv * 4 + r;
+                for (int r = 0; r < DW_RW; ++r) {
+                    const int gy = y0 + wv * DW_RW + r;
                     if (gy < H) {
                         const size_t oidx = plane + (size_t)gy * W + gx;
                         out[oidx] = addt ? o[r][h] + addt[oidx] : o[r][h];
