@@ -160,36 +160,37 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
     constexpr int C1B_PF = 4;                                          // k-steps of B operands in flight per wave
     const int nks_pad = (nks + C1B_PF - 1) / C1B_PF * C1B_PF;          // the k-loop is branch-free: padded steps multiply zeros
 
-    // ---- weights -> LDS, once: element (ci, co) lands at [(ci >> 2) * MTT + (co >> 4)][(ci & 3) * 16 + (co & 15)].
-    // The packed image is read linearly (coalesced), ten independent loads per thread in flight; the zero padding of
-    // the k-steps beyond C_in is written first.
+    // ---- weights -> LDS, once: element (ci, local channel cl) lands at [(ci >> 2) * MTT + (cl >> 4)][(ci & 3) * 16 +
+    // (cl & 15)]; ten independent loads per thread in flight; the zero padding of the k-steps beyond C_in is written first.
+    // blockIdx.y picks the block of MTT m-tiles this workgroup computes (small launches split the output channels over
+    // workgroups: a lone 256-pixel tile per CU would otherwise walk all C_out / 16 m-tiles -- and stage the whole weight
+    // matrix -- alone)
+    const int co0 = blockIdx.y * (MTT * 16);
     for (int e = tid; e < nks_pad * MTT * 64; e += C1_THREADS) smem[e] = 0.f;
     __syncthreads();
     {
-        const int per_cb = p.nch1 * KC * CO_LDS;                        // floats per output-channel block
-        const int total = (MTT / 5) * per_cb;
+        const int total = p.nch1 * KC * (MTT * 16);                     // (ci, local channel), the channel fastest
         for (int e0 = 0; e0 < total; e0 += C1_THREADS * 10) {
             float v[10];
 #pragma unroll
             for (int u = 0; u < 10; ++u) {
                 const int e = e0 + u * C1_THREADS + tid;
-                v[u] = e < total ? p.w1[e] : 0.f;
+                const int ci = e / (MTT * 16), cl = e - ci * (MTT * 16);
+                const int co = co0 + cl, cb = co / 80, col = co - cb * 80;
+                v[u] = e < total ? p.w1[((size_t)cb * p.nch1 * KC + ci) * CO_LDS + col] : 0.f;
             }
 #pragma unroll
             for (int u = 0; u < 10; ++u) {
                 const int e = e0 + u * C1_THREADS + tid;
-                const int cb = e >= per_cb ? 1 : 0;
-                const int r = e - cb * per_cb;
-                const int ci = r / CO_LDS, col = r - ci * CO_LDS;
-                const int co = cb * 80 + col;
-                if (e < total && ci < Cin) smem[((ci >> 2) * MTT + (co >> 4)) * 64 + (ci & 3) * 16 + (co & 15)] = v[u];
+                const int ci = e / (MTT * 16), cl = e - ci * (MTT * 16);
+                if (e < total && ci < Cin) smem[((ci >> 2) * MTT + (cl >> 4)) * 64 + (ci & 3) * 16 + (cl & 15)] = v[u];
             }
         }
     }
     // bias -> LDS too: the epilogue needs 4 * MTT per-lane values per tile, and a global load each would be 4 * MTT
     // serial memory round trips per tile
     float* sbias = smem + nks_pad * MTT * 64;
-    for (int e = tid; e < MTT * 16; e += C1_THREADS) sbias[e] = p.bias ? p.bias[e] : 0.f;
+    for (int e = tid; e < MTT * 16; e += C1_THREADS) sbias[e] = p.bias ? p.bias[co0 + e] : 0.f;
     __syncthreads();
 
     // The B-operand stream runs ACROSS tiles: the last C1B_PF k-steps of a tile load the first k-steps of the next one,
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
         auto fetch = [&](int mt, int slot) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                unsigned o = px0 < HW ? (unsigned)((mt * 16 + kq * 4 + r) * HW + px0) * 4u : OOB;
+                unsigned o = px0 < HW ? (unsigned)((co0 + mt * 16 + kq * 4 + r) * HW + px0) * 4u : OOB;
                 asm volatile("" : "+v"(o));
                 off[slot][r] = o;
                 if (C1B_ABL & 4) { rv[slot][r] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
                 const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = mt * 16 + kq * 4 + r;                 // (< C_out = MTT * 16 by construction)
+                    const int co = co0 + mt * 16 + kq * 4 + r;           // (< C_out by construction)
                     const size_t o = samp + (size_t)co * HW + px0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -343,10 +344,13 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
 }
 
 template <int MTT>
-inline void conv1x1_all_launch(const ConvArgs& a, unsigned grid, size_t lds, int tpi, int ntiles, hipStream_t st) {
+inline void conv1x1_all_launch(const ConvArgs& a, int tpi, int ntiles, hipStream_t st) {
     // (H*W % 4 != 0 stays on the first-generation kernel: the TAIL = 1 instantiation measured no faster -- 80+ spilled
     // registers around its scalar tail path)
-#define C1B_GO(ACT, RES) hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), dim3(grid), dim3(C1_THREADS), lds, st, a, tpi, ntiles)
+    const size_t lds = ((size_t)((a.Cin2 + 15) / 16 * 4) * MTT * 64 + MTT * 16) * sizeof(float);   // k-steps padded to 4, + bias
+    const int cus = 256;
+    const dim3 grid((unsigned)(ntiles < 2 * cus ? ntiles : 2 * cus), (unsigned)(a.Cout / (MTT * 16)));
+#define C1B_GO(ACT, RES) hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), grid, dim3(C1_THREADS), lds, st, a, tpi, ntiles)
     const int res = a.resid != nullptr;
     switch ((a.act & 0xff) * 2 + res) {
         case 0: C1B_GO(0, 0); break;
@@ -378,13 +382,14 @@ inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
     const int tpi = (HW + C1_PIX - 1) / C1_PIX;
     const dim3 grid((unsigned)(a.B * tpi), (unsigned)a.coblks);
     const int mtt = mt * a.coblks;
-    const size_t lds2 = ((size_t)((a.Cin2 + 15) / 16 * 4) * mtt * 64 + mtt * 16) * sizeof(float);   // k-steps padded to a multiple of 4, + bias
-    if (SINDDM_CONV1X1_V2 && mt == 5 && (mtt == 5 || mtt == 10) && a.Cout == mtt * 16 && lds2 <= 64 * 1024 && HW % 4 == 0) {
+    if (SINDDM_CONV1X1_V2 && mt == 5 && (mtt == 5 || mtt == 10) && a.Cout == mtt * 16 && HW % 4 == 0 && a.Cin2 <= 160) {
         const int ntiles = a.B * tpi;
-        const int cus = 256;
-        const unsigned g2 = (unsigned)(ntiles < 2 * cus ? ntiles : 2 * cus);
-        if (mtt == 10) conv1x1_all_launch<10>(a, g2, lds2, tpi, ntiles, st);
-        else conv1x1_all_launch<5>(a, g2, lds2, tpi, ntiles, st);
+        // enough pixel tiles to fill the chip: every workgroup computes all output channels (input read once);
+        // fewer: the channels are split over workgroups -- 80 per workgroup, then 16 (coarse scales at small batch)
+        const size_t lds_all = ((size_t)((a.Cin2 + 15) / 16 * 4) * mtt * 64 + mtt * 16) * sizeof(float);
+        if (ntiles >= 512 && mtt == 10 && lds_all <= 64 * 1024) conv1x1_all_launch<10>(a, tpi, ntiles, st);
+        else if (ntiles >= 128) conv1x1_all_launch<5>(a, tpi, ntiles, st);
+        else conv1x1_all_launch<1>(a, tpi, ntiles, st);
     } else
     switch (mt) {
         case 5: { constexpr size_t lds = 2 * (C1_KC * ConvCfg<5, 4>::CO_LDS + C1_KC * C1_PS) * sizeof(float);
