@@ -157,6 +157,22 @@ def test_c2_benchmarked_batch_vs_oracle():
     assert hw == (186, 248) and total_t == 228
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 48, 64), (1, 94, 126), (3, 48, 64), (16, 48, 64)])
+def test_small_launch_geometries_dim160_vs_oracle(B, H, W):
+    """Coarse scales at small batch take different launch geometries of the same kernels: one m-tile per Winograd work
+    item, the 1x1 projections with their output channels split over workgroups (16 or 80 per workgroup), the first conv
+    with its channel walk split over blockIdx.z.  One network evaluation per geometry against the oracle."""
+    net, d = build_diffusion("C2", dim=160, device=torch.device(DEV))
+    sd = closed_form_state_dict(160)
+    x = hash_randn((B, 3, H, W), 4242) * 0.8
+    t = torch.tensor([(37 * (i + 1)) % 1000 for i in range(B)], dtype=torch.long)
+    got = net.infer(x.to(DEV), t.to(DEV), 0, 1.0).cpu()
+    idx = sorted({0, B - 1})
+    ref = O.net_forward(sd, x[idx], t[idx], 1.0)
+    err = rel_l2(got[idx], ref)
+    assert err < 1e-5, (B, H, W, err)
+
+
 def test_full_chain_c2_t1000_golden(golden):
     """G14: the headline chain length.  5 scales, T=1000, B=1, dim=160: 2 478 chained network evaluations through
     the public sample()/sample_via_scale() API with hash noise vs the REFERENCE's images (north_star: 1e-4 rel-L2).
