@@ -9,6 +9,9 @@ namespace sinddm {
 
 // Kernel-selection switches are COMPILE-TIME macros (A/B builds: tools/build_variant.sh <name> -D...): the shipped
 // library reads no environment variable, so nothing outside the caller's arguments can change which kernel a call runs.
+#ifndef SINDDM_WINO_V3        // 1: inference 3x3 convs of big launches on the F(2x4,3x3) kernel (conv_wino3.h)
+#define SINDDM_WINO_V3 1
+#endif
 #ifndef SINDDM_CONV_WINO      // 1: 3x3 convs (C_in >= 8) on the Winograd kernel, 0: direct implicit-GEMM kernel
 #define SINDDM_CONV_WINO 1
 #endif

@@ -26,6 +26,8 @@ struct BlockPlan {
     // Winograd F(2x2,3x3) images (register layout [coblk][chunk of 16 ci][xi][ks][mt][lane])
     int nchw1, nchw2;          // 16-channel chunks of conv1 / conv2
     int64_t pk_wc1, pk_wc2;    // pk_wc1 = -1 when conv1 stays on the direct kernel (C_in < 8)
+    // Winograd F(2x4,3x3) images of conv_wino3.h ([coblk][chunk][i][ks][q 0..7][lane][4]); -1 = shape not supported
+    int64_t pk_w1f, pk_w2f;
     int cond_off;  // offset of this block's per-sample bias inside the cond vector
 };
 
@@ -95,6 +97,10 @@ inline NetPlan make_plan(int dim) {
         b.nchw2 = (b.cout + 15) / 16;
         if (b.cin >= 8) { b.pk_wc1 = q; q += (int64_t)b.coblks * b.nchw1 * 16 * 4 * b.mt * 64; } else b.pk_wc1 = -1;
         b.pk_wc2 = q; q += (int64_t)b.coblks * b.nchw2 * 16 * 4 * b.mt * 64;
+        // (32768 floats per (co-block, chunk): 4 waves x 4 k-steps x 8 groups x 64 lanes x 4)
+        const bool f24 = b.mt == 5 && b.cout % 80 == 0;
+        if (f24 && b.cin >= 16 && b.cin % 16 == 0) { b.pk_w1f = q; q += (int64_t)b.coblks * b.nchw1 * 32768; } else b.pk_w1f = -1;
+        if (f24 && b.cout % 16 == 0) { b.pk_w2f = q; q += (int64_t)b.coblks * b.nchw2 * 32768; } else b.pk_w2f = -1;
         b.cond_off = coff;
         coff += b.cin;
     }

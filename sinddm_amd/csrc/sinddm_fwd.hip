@@ -2,6 +2,7 @@
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
 #include "conv_wino.h"
+#include "conv_wino3.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -92,6 +93,35 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
             }
             v = (SINDDM_WINO_V2 && fi == 2) ? -acc : acc;
         }
+    } else if (g.kind == 4) {
+        // Winograd F(2x4,3x3) of conv_wino3.h: U = G2 g G4^T, register image [coblk][chunk][i][ks][q][lane][slot];
+        // (q, slot) -> pair e = 4 q + slot = mt * 6 + j (pairs 30, 31 are padding); vertical row 2 stored negated
+        long long r = j;
+        const int slot = (int)(r % 4); r /= 4;
+        const int lane = (int)(r % 64); r /= 64;
+        const int q8 = (int)(r % 8); r /= 8;
+        const int ks = (int)(r % 4); r /= 4;
+        const int fi = (int)(r % 4); r /= 4;
+        const int ch = (int)(r % g.nch); r /= g.nch;
+        const int cb = (int)r;
+        const int e = q8 * 4 + slot;
+        const int mt = e / 6, fj = e - mt * 6;
+        const int m = cb * 80 + mt * 16 + (lane & 15);
+        const int k = ch * 16 + ks * 4 + (lane >> 4);
+        if (e < 30 && m < g.cout && k < g.cin) {
+            const double G2[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
+            const double G4[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                                     {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+            double acc = 0.;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double rowv = 0.;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) rowv += G4[fj][b2] * (double)params[g.w + ((long long)m * g.cin + k) * 9 + a * 3 + b2];
+                acc += G2[fi][a] * rowv;
+            }
+            v = (float)(fi == 2 ? -acc : acc);
+        }
     } else if (g.kind == 1) {
         if (j < g.cout) {
             v = params[g.w + j];
@@ -153,7 +183,32 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
     add(z);
     a.nseg = n;
     a.total = total;
-    return pack_launch(params, packed, a, st);
+    int rc = pack_launch(params, packed, a, st);
+    if (rc) return rc;
+    // second launch: the F(2x4) Winograd images of conv_wino3.h
+    PackArgs f{};
+    n = 0;
+    total = 0;
+    auto addf = [&](PackSeg sg) { f.seg[n++] = sg; total += sg.count; };
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        PackSeg wz{};
+        wz.kind = 4; wz.mt = b.mt; wz.transpose = 0; wz.w2 = -1; wz.taps = 9;
+        if (b.pk_w1f >= 0) {
+            wz.dst = b.pk_w1f; wz.nch = b.nchw1; wz.count = (long long)b.coblks * b.nchw1 * 32768;
+            wz.w = b.c1_w; wz.cin = b.cin; wz.cout = b.cout;
+            addf(wz);
+        }
+        if (b.pk_w2f >= 0) {
+            wz.dst = b.pk_w2f; wz.nch = b.nchw2; wz.count = (long long)b.coblks * b.nchw2 * 32768;
+            wz.w = b.c2_w; wz.cin = b.cout; wz.cout = b.cout;
+            addf(wz);
+        }
+    }
+    if (n == 0) return 0;
+    f.nseg = n;
+    f.total = total;
+    return pack_launch(params, packed, f, st);
 }
 
 // =====================================================================================
@@ -729,7 +784,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
         constexpr int c3 = SINDDM_CONV_C3;
-        if (wino && b.pk_wc1 >= 0) {
+        // inference launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
+        const bool v3 = SINDDM_WINO_V3 && wino && !tb && W % 4 == 0 &&
+                        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= 2 * wino2_cu_count();
+        if (v3 && b.pk_w1f >= 0) {
+            c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
+            rc = conv_wino3_launch(c1, st);
+        } else if (wino && b.pk_wc1 >= 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);
         } else if (b.cin == 3 && c3) {
@@ -763,8 +824,14 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
             } else {
                 c2.resid = cur; c2.bias = packed + b.pk_b2;
             }
-            c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2; c2.nch1 = 0;
-            rc = conv_wino_launch(c2, b.mt, st);
+            c2.nch1 = 0;
+            if (v3 && b.pk_w2f >= 0) {
+                c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
+                rc = conv_wino3_launch(c2, st);
+            } else {
+                c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2;
+                rc = conv_wino_launch(c2, b.mt, st);
+            }
         } else {
             c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.nch3 = b.nch2;
             if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
