@@ -18,7 +18,7 @@
 //     (m-tile, frequency) pairs 4q .. 4q+3;
 //   * output transform: the column half (A4^T, 6 -> 4 values) in registers, the row half (A2^T over the four waves)
 //     through LDS, 32 channels per pass; a reader thread owns one 2x4 tile of two channels: 16-byte stores.
-// Restrictions (conv_wino_launch falls back to conv_wino2 otherwise): C_out % 80 == 0, C_in % 16 == 0, W % 4 == 0,
+// Restrictions (the caller falls back to conv_wino2 otherwise): C_out % 80 == 0, C_in % 16 == 0,
 // epilogues ACT 0 / 1 (bias, GELU, residual), launches with at least one item per workgroup slot.
 #pragma once
 #include "conv_wino2.h"
@@ -36,7 +36,9 @@ constexpr int W3_CH_BYTES = 4 * 4 * W3_KS_BYTES;   // ... of one 16-channel chun
 // floats of the packed F(2x4) image of one conv
 inline long long wino3_packed_floats(int coblks, int nch) { return (long long)coblks * nch * (W3_CH_BYTES / 4); }
 
-template <int ACT>
+// EDGE: 0 when W % 4 == 0; 1 when W % 4 == 2 (patch columns past the row end are masked, 8-byte edge stores); 2 when W
+// is odd (4-byte edge stores)
+template <int ACT, int EDGE>
 __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
     constexpr int MT = W3_MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,14 +89,18 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
 
     const int nch = p.nch3;
 
-    // ---- raw tile staging (identical to conv_wino2: W % 4 == 0, so no column masks) ----
+    // ---- raw tile staging (as conv_wino2) ----
     constexpr unsigned OOB = 0x40000000u;
     unsigned goff;
+    bool cm[6], cmn[6];                             // patch column c of this lane's tile lies inside the image (item / next item)
     auto make_goff = [&](const Wino2Item& it) {
         const int row = lane / W2_GRP, grp = lane - row * W2_GRP;
         const int gy = it.y0 + row - 1, gx = it.x0 - 4 + 4 * grp;
         const bool ok = lane < W2_HR * W2_GRP && gy >= 0 && gy < H && gx >= 0 && gx < W;
         goff = ok ? (unsigned)(gy * W + gx) * 4u : OOB;
+        // (a 16-byte group that starts inside the image may run past its right edge into the next row when W % 4 != 0)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cmn[c] = it.x0 + 4 * tc_ - 1 + c < W;
     };
     typedef __attribute__((address_space(3))) void* lds_ptr;
     auto issue_dma = [&](int ib, int c, float* buf) {            // prologue only: chunk c of sample ib by LDS-DMA
@@ -139,10 +145,13 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
             rb[c] = qb[c];
         }
     };
-    auto transform = [&](const float (&ra)[6], const float (&rb)[6], float (&v)[W3_NF]) {
+    auto transform = [&](const float (&ra)[6], const float (&rb)[6], float (&v)[W3_NF], const bool (&mk)[6]) {
         float r[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) r[c] = fmaf(sgn, rb[c], ra[c]);
+        for (int c = 0; c < 6; ++c) {
+            r[c] = fmaf(sgn, rb[c], ra[c]);
+            if (EDGE) r[c] = mk[c] ? r[c] : 0.f;
+        }
         // F(4,3) B^T:  [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
         const float s24 = r[4] - 4.f * r[2], s13 = r[3] - 4.f * r[1];          // r4 - 4 r2,  r3 - 4 r1
         const float u24 = r[4] - r[2], u13 = 2.f * (r[3] - r[1]);              // r4 - r2,  2 (r3 - r1)
@@ -158,6 +167,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
     int l = 0;
     if (!decode(l, it)) return;
     make_goff(it);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cm[c] = cmn[c];
     issue_dma(it.b, 0, smem);
     int wb_it = wbase(it.cb);
 #pragma unroll
@@ -171,7 +182,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
     {
         float ra[6], rb[6];
         read_raw(smem, ra, rb);
-        transform(ra, rb, v[0]);
+        transform(ra, rb, v[0], cm);
     }
 
     for (;;) {
@@ -213,7 +224,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 read_raw(rsrc_, ra, rb);
                 if (ks == 0) { stage_load(0, 0); stage_load(1, 1); }
                 if (ks == 1) { stage_load(0, 2); stage_load(1, 3); }
-                transform(ra, rb, v[(ks + 1) & 1]);
+                // (the operands built in k-step 3 of the last chunk belong to the next item's tile)
+                bool mk[6];
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) mk[cc] = (ks == 3 && last) ? cmn[cc] : cm[cc];
+                transform(ra, rb, v[(ks + 1) & 1], mk);
                 __builtin_amdgcn_sched_barrier(0);
                 // burst: 30 MFMAs, the A group of four (m-tile, frequency) pairs refilled right behind them
 #pragma unroll
@@ -268,6 +283,39 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
             asm volatile("" : "+v"(o));
             return o;
         };
+        // 4 pixels per access; at the right image edge (EDGE builds) in 8- or 4-byte pieces with per-piece validity
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        auto piece_off = [&](unsigned o, int px) -> unsigned {          // offset of pixel px of the quad, or OOB
+            unsigned q = (o != OOB && x + px < W) ? o + 4u * px : OOB;
+            asm volatile("" : "+v"(q));
+            return q;
+        };
+        auto ld4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o) -> f32x4 {
+            if constexpr (EDGE == 0) {
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)o, 0, 0));
+            } else if constexpr (EDGE == 1) {
+                const u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(r, (int)piece_off(o, 0), 0, 0);
+                const u32x2 a1 = __builtin_amdgcn_raw_buffer_load_b64(r, (int)piece_off(o, 2), 0, 0);
+                return __builtin_bit_cast(f32x4, u32x4{a0[0], a0[1], a1[0], a1[1]});
+            } else {
+                f32x4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)piece_off(o, e), 0, 0));
+                return t;
+            }
+        };
+        auto st4 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned o, f32x4 vv) {
+            const u32x4 u = __builtin_bit_cast(u32x4, vv);
+            if constexpr (EDGE == 0) {
+                __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)o, 0, 0);
+            } else if constexpr (EDGE == 1) {
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{u[0], u[1]}, r, (int)piece_off(o, 0), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{u[2], u[3]}, r, (int)piece_off(o, 2), 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(u[e], r, (int)piece_off(o, e), 0, 0);
+            }
+        };
         f32x4 rs_v[2][2];
         float bs_v[2];
         auto prefetch = [&](int m0) {
@@ -277,8 +325,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 bs_v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     rs_bias, (it.cb * (MT * 16) + m0 * 16 + cg + 16 * k) * 4, 0, 0));
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
-                    rs_v[k][pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (int)off_of(m0, k, pp), 0, 0));
+                for (int pp = 0; pp < 2; ++pp) rs_v[k][pp] = ld4(rs_res, off_of(m0, k, pp));
             }
         };
 #pragma unroll
@@ -330,13 +377,14 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
             for (int k = 0; k < 2; ++k) {
                 if (!in_block(m0, k)) continue;
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val[k][pp]), rs_out, (int)off_of(m0, k, pp), 0, 0);
+                for (int pp = 0; pp < 2; ++pp) st4(rs_out, off_of(m0, k, pp), val[k][pp]);
             }
         }
         if (!have_next) break;
         it = nx;                                   // goff already describes nx
         wb_it = wb_nx;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cm[c] = cmn[c];
     }
 }
 
@@ -363,8 +411,17 @@ inline int conv_wino3_launch(const ConvArgs& a_in, hipStream_t st) {
     if (wpx > ipx) wpx = ipx;
     const unsigned grid = (unsigned)(wpx * 8);
     constexpr size_t lds = W2_LDS_FLOATS * sizeof(float);
-    if ((a.act & 0xff) == 1) hipLaunchKernelGGL((conv_wino3_kernel<1>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx);
-    else hipLaunchKernelGGL((conv_wino3_kernel<0>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx);
+#define W3_GO(ACT, EDGE) hipLaunchKernelGGL((conv_wino3_kernel<ACT, EDGE>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx)
+    const int edge = a.W % 4 == 0 ? 0 : (a.W % 2 == 0 ? 1 : 2);
+    switch (((a.act & 0xff) == 1 ? 3 : 0) + edge) {
+        case 0: W3_GO(0, 0); break;
+        case 1: W3_GO(0, 1); break;
+        case 2: W3_GO(0, 2); break;
+        case 3: W3_GO(1, 0); break;
+        case 4: W3_GO(1, 1); break;
+        default: W3_GO(1, 2);
+    }
+#undef W3_GO
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
