@@ -1,4 +1,5 @@
-// Winograd F(2x4, 3x3) 3x3 convolution on the gfx950 fp32 matrix cores -- third generation, inference forward only.
+// Winograd F(2x4, 3x3) 3x3 convolution on the gfx950 fp32 matrix cores -- third generation (forward and data gradient
+// of the big launches).
 //
 // The vertical direction keeps F(2,3) (2 output rows from 4 patch rows), the horizontal one uses F(4,3) (4 output
 // columns from 6 patch columns): 4 x 6 = 24 frequencies per 2x4 output tile = 3 multiplies per output instead of the
@@ -19,7 +20,7 @@
 //   * output transform: the column half (A4^T, 6 -> 4 values) in registers, the row half (A2^T over the four waves)
 //     through LDS, 32 channels per pass; a reader thread owns one 2x4 tile of two channels: 16-byte stores.
 // Restrictions (the caller falls back to conv_wino2 otherwise): C_out % 80 == 0, C_in % 16 == 0,
-// epilogues ACT 0 / 1 (bias, GELU, residual), launches with at least one item per workgroup slot.
+// launches with at least one item per workgroup slot.  Same epilogue contract as conv_wino2.h.
 #pragma once
 #include "conv_wino2.h"
 
@@ -270,6 +271,8 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                                                      base ? samp_b : 0u, 0x00020000);
         };
         const __amdgpu_buffer_rsrc_t rs_out = rsrc_of(p.out), rs_res = rsrc_of(p.resid);
+        const __amdgpu_buffer_rsrc_t rs_aux = rsrc_of(ACT == 2 ? p.aux : nullptr);
+        const __amdgpu_buffer_rsrc_t rs_pre = rsrc_of(ACT == 1 ? p.out_pre : nullptr);
         const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
         const bool pix_ok = (y < H) & (x < W);
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 for (int e = 0; e < 4; ++e) __builtin_amdgcn_raw_buffer_store_b32(u[e], r, (int)piece_off(o, e), 0, 0);
             }
         };
-        f32x4 rs_v[2][2];
+        f32x4 rs_v[2][2], ax_v[2][2];
         float bs_v[2];
         auto prefetch = [&](int m0) {
 #pragma unroll
@@ -325,7 +328,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 bs_v[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                     rs_bias, (it.cb * (MT * 16) + m0 * 16 + cg + 16 * k) * 4, 0, 0));
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) rs_v[k][pp] = ld4(rs_res, off_of(m0, k, pp));
+                for (int pp = 0; pp < 2; ++pp) {
+                    const unsigned o = off_of(m0, k, pp);
+                    rs_v[k][pp] = ld4(rs_res, o);
+                    if (ACT == 2) ax_v[k][pp] = ld4(rs_aux, o);
+                }
             }
         };
 #pragma unroll
@@ -366,8 +373,12 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 for (int pp = 0; pp < 2; ++pp) {
                     f32x4 w_ = yv[k][pp] + bs_v[k];
                     if (ACT == 1) {
+                        yv[k][pp] = w_;                            // pre-activation (the training forward saves it)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w_[e] = gelu_erf(w_[e]);
+                    } else if (ACT == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w_[e] *= gelu_erf_grad(ax_v[k][pp][e]);
                     }
                     val[k][pp] = w_ + rs_v[k][pp];
                 }
@@ -377,7 +388,11 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
             for (int k = 0; k < 2; ++k) {
                 if (!in_block(m0, k)) continue;
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) st4(rs_out, off_of(m0, k, pp), val[k][pp]);
+                for (int pp = 0; pp < 2; ++pp) {
+                    const unsigned o = off_of(m0, k, pp);
+                    if (ACT == 1) st4(rs_pre, o, yv[k][pp]);       // (empty descriptor when out_pre is null: dropped)
+                    st4(rs_out, o, val[k][pp]);
+                }
             }
         }
         if (!have_next) break;
@@ -413,13 +428,16 @@ inline int conv_wino3_launch(const ConvArgs& a_in, hipStream_t st) {
     constexpr size_t lds = W2_LDS_FLOATS * sizeof(float);
 #define W3_GO(ACT, EDGE) hipLaunchKernelGGL((conv_wino3_kernel<ACT, EDGE>), dim3(grid), dim3(W2_THREADS), lds, st, a, ipx, wpx)
     const int edge = a.W % 4 == 0 ? 0 : (a.W % 2 == 0 ? 1 : 2);
-    switch (((a.act & 0xff) == 1 ? 3 : 0) + edge) {
+    switch ((a.act & 0xff) * 3 + edge) {
         case 0: W3_GO(0, 0); break;
         case 1: W3_GO(0, 1); break;
         case 2: W3_GO(0, 2); break;
         case 3: W3_GO(1, 0); break;
         case 4: W3_GO(1, 1); break;
-        default: W3_GO(1, 2);
+        case 5: W3_GO(1, 2); break;
+        case 6: W3_GO(2, 0); break;
+        case 7: W3_GO(2, 1); break;
+        default: W3_GO(2, 2);
     }
 #undef W3_GO
     if (rec) {

@@ -5,6 +5,7 @@
 // (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
 #include "conv_mfma.h"
 #include "conv_wino.h"
+#include "conv_wino3.h"
 #include "internal.h"
 #include "wgrad_wino.h"
 
@@ -863,6 +864,7 @@ struct BwdPack {
     // per block: dgrad of conv2 (cout->cout), dgrad of conv1 (cout->cin), dgrad of res 1x1 (cout->cin)
     long long dg2[4], dg1[4], dres[4], dfin, zero;
     long long wdg2[4], wdg1[4];     // Winograd images of the 3x3 data-gradient convs (wdg1 = -1: stays direct)
+    long long wdg2f[4], wdg1f[4];   // their F(2x4) images (conv_wino3.h), -1 = shape not supported
     long long total;
     int mt2[4], mt1[4], cb2[4], cb1[4];
     int mtf, cbf;
@@ -889,6 +891,14 @@ static BwdPack make_bwd_pack(const NetPlan& P) {
         k.wdg2[l] = q; q += (long long)k.cb2[l] * nchW * 16 * 4 * k.mt2[l] * 64;
         if (b.cin >= 8) { k.wdg1[l] = q; q += (long long)k.cb1[l] * nchW * 16 * 4 * k.mt1[l] * 64; }
         else k.wdg1[l] = -1;
+    }
+    // F(2x4) Winograd images of the data-gradient convs (conv_wino3.h): 80-channel row blocks, K = forward cout % 16 == 0
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        const int nchW = (b.cout + 15) / 16;
+        const bool kok = b.cout % 16 == 0;
+        if (kok && k.mt2[l] == 5 && b.cout % 80 == 0) { k.wdg2f[l] = q; q += (long long)k.cb2[l] * nchW * 32768; } else k.wdg2f[l] = -1;
+        if (kok && k.mt1[l] == 5 && b.cin % 80 == 0) { k.wdg1f[l] = q; q += (long long)k.cb1[l] * nchW * 32768; } else k.wdg1f[l] = -1;
     }
     k.zero = q; q += 64;
     k.total = q;
@@ -938,8 +948,29 @@ static int pack_backward(const NetPlan& P, const float* params, float* packed, h
     }
     a.nseg = n;
     a.total = total;
-    // segments are laid out back to back in `packed` in the same order -> dst offsets are cumulative
-    return pack_launch(params, packed, a, st);
+    int rc = pack_launch(params, packed, a, st);
+    if (rc) return rc;
+    PackArgs f{};
+    n = 0;
+    total = 0;
+    auto addf = [&](long long dst, long long w, int fcin, int fcout, int coblks) {
+        PackSeg s{};
+        s.kind = 4; s.transpose = 1; s.w2 = -1; s.taps = 9; s.mt = 5;
+        s.dst = dst; s.w = w; s.cin = fcin; s.cout = fcout;
+        s.nch = (fcout + 15) / 16;
+        s.count = (long long)coblks * s.nch * 32768;
+        f.seg[n++] = s;
+        total += s.count;
+    };
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        if (k.wdg2f[l] >= 0) addf(k.wdg2f[l], b.c2_w, b.cout, b.cout, k.cb2[l]);
+        if (k.wdg1f[l] >= 0) addf(k.wdg1f[l], b.c1_w, b.cin, b.cout, k.cb1[l]);
+    }
+    if (n == 0) return 0;
+    f.nseg = n;
+    f.total = total;
+    return pack_launch(params, packed, f, st);
 }
 
 // =====================================================================================
@@ -988,13 +1019,19 @@ static int conv1x1_or_3x3(const float* zero, const float* in3, int cin3, const f
     return conv_launch(c, mt, st);
 }
 
-static int conv3x3_wino(const float* zero, const float* in3, int cin3, const float* ww, const float* aux, int act,
-                        float* out, int Cout, int mt, int coblks, int B, int H, int W, hipStream_t st) {
+// `wf`: the F(2x4) image of the same conv (or nullptr): big launches take conv_wino3.h
+static int conv3x3_wino(const float* zero, const float* in3, int cin3, const float* ww, const float* wf, const float* aux,
+                        int act, float* out, int Cout, int mt, int coblks, int B, int H, int W, hipStream_t st) {
     ConvArgs c{};
     c.zero = zero;
     c.in = in3; c.Cin = cin3; c.w3 = ww; c.nch3 = (cin3 + 15) / 16; c.nch1 = 0;
     c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
     c.B = B; c.H = H; c.W = W;
+    if (SINDDM_WINO_V3 && wf && mt == 5 &&
+        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= 2 * wino2_cu_count()) {
+        c.w3 = wf;
+        return conv_wino3_launch(c, st);
+    }
     return conv_wino_launch(c, mt, st);
 }
 
@@ -1028,7 +1065,8 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         }
         // dU = dgrad_conv2(dO) * GELU'(u)
         if (wino_enabled())
-            rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], tb.u[l], 2, dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
+            rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], k.wdg2f[l] >= 0 ? packed_bwd + k.wdg2f[l] : nullptr, tb.u[l], 2,
+                              dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
         else
             rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU,
                                 b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
@@ -1037,7 +1075,8 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
         if (rc) return rc;
         if (wino_enabled() && k.wdg1[l] >= 0)
-            rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], nullptr, 0, dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
+            rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], k.wdg1f[l] >= 0 ? packed_bwd + k.wdg1f[l] : nullptr, nullptr, 0,
+                              dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
         else
             rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH,
                                 b.cin, k.mt1[l], k.cb1[l], B, H, W, st);

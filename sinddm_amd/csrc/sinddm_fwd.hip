@@ -108,7 +108,8 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
         const int mt = e / 6, fj = e - mt * 6;
         const int m = cb * 80 + mt * 16 + (lane & 15);
         const int k = ch * 16 + ks * 4 + (lane >> 4);
-        if (e < 30 && m < g.cout && k < g.cin) {
+        const int M4 = g.transpose ? g.cin : g.cout, K4 = g.transpose ? g.cout : g.cin;
+        if (e < 30 && m < M4 && k < K4) {
             const double G2[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
             const double G4[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
                                      {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
@@ -117,7 +118,9 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
             for (int a = 0; a < 3; ++a) {
                 double rowv = 0.;
 #pragma unroll
-                for (int b2 = 0; b2 < 3; ++b2) rowv += G4[fj][b2] * (double)params[g.w + ((long long)m * g.cin + k) * 9 + a * 3 + b2];
+                for (int b2 = 0; b2 < 3; ++b2)
+                    rowv += G4[fj][b2] * (double)(g.transpose ? params[g.w + ((long long)k * g.cin + m) * 9 + (2 - a) * 3 + (2 - b2)]
+                                                              : params[g.w + ((long long)m * g.cin + k) * 9 + a * 3 + b2]);
                 acc += G2[fi][a] * rowv;
             }
             v = (float)(fi == 2 ? -acc : acc);
@@ -784,8 +787,8 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
         c1.out_pre = tb ? tb->u[l] : nullptr;
         constexpr int c3 = SINDDM_CONV_C3;
-        // inference launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
-        const bool v3 = SINDDM_WINO_V3 && wino && !tb &&
+        // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
+        const bool v3 = SINDDM_WINO_V3 && wino &&
                         (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= 2 * wino2_cu_count();
         if (v3 && b.pk_w1f >= 0) {
             c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
