@@ -40,7 +40,7 @@ def main(prefix, tag):
             continue
         algb = sum(4.0 * (ci + co) * alg[cfg] for ci, co in chans) / len(chans)
         out[cfg.upper()] = {
-            "kernel": "conv_wino2_kernel<5,*> (7 launches per step pooled)", "launches_sampled": n,
+            "kernel": "conv_wino*_kernel (the 7 Winograd launches of a step pooled)", "launches_sampled": n,
             "source": f"profiles/{tag}_pmc_{cfg}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB)",
             "fetch_size_bytes_raw": fetch * 1024, "write_size_bytes_raw": write * 1024,
             "fetch_size_bytes_x2": 2 * fetch * 1024,
