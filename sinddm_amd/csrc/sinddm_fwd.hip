@@ -407,8 +407,86 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     }
 }
 
+// Register-window variant for rows that are a multiple of 4 pixels (16-byte aligned): no LDS, no barrier.  A lane owns 4
+// consecutive output columns of DWR_ROWS output rows and slides over the DWR_ROWS + 4 input rows: per input row three
+// aligned 16-byte loads (columns x-4 .. x+7, eight of them used) feed the five output rows it touches (100 FMAs); the 25
+// taps are wave-uniform (scalar registers).  Every load of a lane is independent of its FMAs, so many rows are in flight
+// per wave and the only dependence on other lanes is the L1 (the halo columns of the neighbours).
+#ifndef DWR_ROWS_
+#define DWR_ROWS_ 12
+#endif
+constexpr int DWR_ROWS = DWR_ROWS_;
+
+__global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ cond,
+                                                            int cond_stride, const float* __restrict__ addt, int flip,
+                                                            float* __restrict__ out, int C, int H, int W, int bandsX) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int by = blockIdx.x / bandsX, bx = blockIdx.x - by * bandsX;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x4 = (bx * 64 + lane) * 4;                     // first output column of this lane
+    const int y0 = (by * 4 + wv) * DWR_ROWS;                 // first output row of this wave
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    float wk[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) wk[k] = w[c * 25 + (flip ? 24 - k : k)];      // (wave-uniform: scalar loads)
+    const float add = (bias ? bias[c] : 0.0f) + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
+    if (y0 >= H) return;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + plane), 0, H * W * 4, 0x00020000);
+    constexpr int OOBI = 0x40000000;
+    const bool colok = x4 < W;
+    // quads left / right of the lane's own: outside the row -> zero (W % 4 == 0: a quad is entirely in or out)
+    const bool lok = colok && x4 >= 4, rok = colok && x4 + 4 < W;
+    f32x4 acc[DWR_ROWS];
+#pragma unroll
+    for (int r = 0; r < DWR_ROWS; ++r) acc[r] = f32x4{add, add, add, add};
+#pragma unroll
+    for (int ir = 0; ir < DWR_ROWS + 4; ++ir) {
+        const int gy = y0 + ir - 2;
+        const bool rowok = gy >= 0 && gy < H;
+        const int base = (gy * W + x4) * 4;
+        const f32x4 ql = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (rowok && lok) ? base - 16 : OOBI, 0, 0));
+        const f32x4 qm = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (rowok && colok) ? base : OOBI, 0, 0));
+        const f32x4 qr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (rowok && rok) ? base + 16 : OOBI, 0, 0));
+        const float in[8] = {ql[2], ql[3], qm[0], qm[1], qm[2], qm[3], qr[0], qr[1]};     // columns x4-2 .. x4+5
+#pragma unroll
+        for (int r = 0; r < DWR_ROWS; ++r) {
+            const int ky = ir - r;                               // input row ir contributes tap row ky to output row r
+            if (ky >= 0 && ky < 5) {
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) acc[r][cc] = fmaf(wk[ky * 5 + kx], in[cc + kx], acc[r][cc]);
+                }
+            }
+        }
+    }
+    if (!colok) return;
+#pragma unroll
+    for (int r = 0; r < DWR_ROWS; ++r) {
+        const int gy = y0 + r;
+        if (gy < H) {
+            const size_t o = plane + (size_t)gy * W + x4;
+            f32x4 v = acc[r];
+            if (addt) v += *reinterpret_cast<const f32x4*>(addt + o);
+            *reinterpret_cast<f32x4*>(out + o) = v;
+        }
+    }
+}
+
+#ifndef SINDDM_DW_ROWS
+#define SINDDM_DW_ROWS 1
+#endif
+
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
                   const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st) {
+    if (SINDDM_DW_ROWS && W % 4 == 0 && W >= 192) {            // (a lane owns 4 columns: narrow images leave most of a wave idle)
+        const int bandsX = (W + 255) / 256, bandsY = (H + 4 * DWR_ROWS - 1) / (4 * DWR_ROWS);
+        hipLaunchKernelGGL(dwconv5_rows_kernel, dim3(bandsX * bandsY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
+                           addt, flip, out, C, H, W, bandsX);
+        SINDDM_LAUNCH_CHECK();
+        return 0;
+    }
     const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
     const int groupsX = (tilesX + DW_NX - 1) / DW_NX;
     hipLaunchKernelGGL(dwconv5_kernel, dim3(groupsX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
