@@ -1028,7 +1028,7 @@ static int conv3x3_wino(const float* zero, const float* in3, int cin3, const flo
     c.aux = aux; c.act = act; c.out = out; c.Cout = Cout; c.coblks = coblks;
     c.B = B; c.H = H; c.W = W;
     if (SINDDM_WINO_V3 && wf && mt == 5 &&
-        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= 2 * wino2_cu_count()) {
+        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count()) {
         c.w3 = wf;
         return conv_wino3_launch(c, st);
     }

@@ -867,7 +867,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         constexpr int c3 = SINDDM_CONV_C3;
         // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
         const bool v3 = SINDDM_WINO_V3 && wino &&
-                        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= 2 * wino2_cu_count();
+                        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
         if (v3 && b.pk_w1f >= 0) {
             c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
             rc = conv_wino3_launch(c1, st);
