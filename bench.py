@@ -192,6 +192,9 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
         "executed_flops_per_launch": round(dom_ex / max(1, dom_n)),
         "algorithmic_flops_per_launch": round(dom_fl / max(1, dom_n)),
         "algorithmic_tflops": round(algorithmic, 2), "algorithmic_speedup": round(algorithmic / executed, 3) if executed > 0 else None,
+        # the same launches priced as the round-1/2 F(2x2,3x3) kernel would execute them (16/36 of the direct FLOPs): only
+        # for comparison with earlier rounds' `frac` -- the F(2x4) kernel executes 24/72 and `frac` above counts that
+        "frac_if_counted_as_f2x2": round(algorithmic * (16.0 / 36.0) / FP32_MFMA_PEAK_TFLOPS, 4),
         "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(dom_n),
         "share_of_step": round(dom_ms / (dt * 1e3), 4),
         "all_mfma_convs": {"algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
