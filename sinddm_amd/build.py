@@ -18,7 +18,9 @@ INCLUDE = os.path.join(HERE, "..", "include")
 LIB = os.path.join(HERE, "libsinddm_hip.so")
 STAMP = LIB + ".sha256"
 SOURCES = ["sinddm_fwd.hip", "sinddm_bwd.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared"]
+# -amdgpu-spill-vgpr-to-agpr=0: conv_wino4.h owns the AGPRs a0..a239 by number (inline asm); a VGPR spill must never land there
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "-amdgpu-spill-vgpr-to-agpr=0",
+         "-fPIC", "-shared"]
 
 
 def _hipcc() -> str:

@@ -15,6 +15,9 @@ namespace sinddm {
 #ifndef SINDDM_V3_MIN_ITEMS_PER_CU   // launches with at least this many (tile, 80-channel block) items per CU take conv_wino3.h
 #define SINDDM_V3_MIN_ITEMS_PER_CU 1
 #endif
+#ifndef SINDDM_WINO_V4        // 1: launches with several 8x32 items per CU on the one-wave-per-SIMD F(2x4,3x3) kernel (conv_wino4.h)
+#define SINDDM_WINO_V4 1
+#endif
 #ifndef SINDDM_CONV_WINO      // 1: 3x3 convs (C_in >= 8) on the Winograd kernel, 0: direct implicit-GEMM kernel
 #define SINDDM_CONV_WINO 1
 #endif

@@ -2,7 +2,7 @@
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
 #include "conv_wino.h"
-#include "conv_wino3.h"
+#include "conv_wino4.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -868,9 +868,11 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
         const bool v3 = SINDDM_WINO_V3 && wino &&
                         (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
+        // ... and the ones with several 8x32 items per CU its one-wave-per-SIMD form (weights shared by two n-tiles)
+        const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
         if (v3 && b.pk_w1f >= 0) {
             c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
-            rc = conv_wino3_launch(c1, st);
+            rc = v4 ? conv_wino4_launch(c1, st) : conv_wino3_launch(c1, st);
         } else if (wino && b.pk_wc1 >= 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);
@@ -908,7 +910,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
             c2.nch1 = 0;
             if (v3 && b.pk_w2f >= 0) {
                 c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
-                rc = conv_wino3_launch(c2, st);
+                rc = v4 ? conv_wino4_launch(c2, st) : conv_wino3_launch(c2, st);
             } else {
                 c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2;
                 rc = conv_wino_launch(c2, b.mt, st);
@@ -1117,6 +1119,11 @@ int sinddm_debug_w2_seg(unsigned long long* host_dst, int n) {
 }
 int sinddm_debug_w2_phase(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_phase), sizeof(unsigned long long) * n);
+}
+#endif
+#ifdef W4_TIMING
+int sinddm_debug_w4_seg(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_seg), sizeof(unsigned long long) * n);
 }
 #endif
 #ifdef W2_TIMING

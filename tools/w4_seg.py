@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Where does a conv_wino4 work item spend its time?  Needs a -DW4_TIMING build at tools/ab/lib<name>.so (argv[1],
+default T): per Winograd launch of one network evaluation (C3 finest scale, batch 8) the s_memtime stamps of every
+workgroup's item 3: main loop, and per epilogue pass (column transform + LDS write | barrier | LDS reads + row
+transform | barrier | activation / residual / stores)."""
+import ctypes as C, os, sys, shutil
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+name = sys.argv[1] if len(sys.argv) > 1 else "T"
+shutil.copy(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so"), "/tmp/lib_keep.so")
+shutil.copy(os.path.join(ROOT, "tools", "ab", f"lib{name}.so"), os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so"))
+try:
+    from sinddm_amd import _lib
+    from sinddm_amd.configs import build_diffusion
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    net, d = build_diffusion("C3", 160, dev)
+    x = torch.randn(8, 3, 411, 512, device=dev)
+    for _ in range(2):
+        y = net.infer(x, None, 10, 5.0)
+    torch.cuda.synchronize()
+    n = 8 * 256 * 4 * 32
+    buf = (C.c_ulonglong * n)()
+    f = C.CDLL(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so")).sinddm_debug_w4_seg
+    f.argtypes = [C.c_void_p, C.c_int]
+    assert f(buf, n) == 0
+    a = np.array(buf, dtype=np.uint64).reshape(8, 256, 4, 32).astype(np.int64)
+    names = ["80->80", "80->160 GELU", "160->160", "160->160 GELU", "160->160", "160->80 GELU", "80->80"]
+    # 7 launches per evaluation, 2 evaluations = 14 launches -> rows (launch % 8); the second evaluation's launches 7..13
+    # overwrite rows 7, 0..5: row of launch j of the 2nd evaluation = (7 + j) % 8
+    for j in range(7):
+        r = a[(7 + j) % 8]
+        ok = r[:, :, 1] > 0
+        t = r[ok]
+        main = t[:, 1] - t[:, 0]
+        epi = t[:, 20] - t[:, 1]
+        print(f"launch {j} {names[j]:14s}: main loop {main.mean():8.0f}  epilogue {epi.mean():7.0f} ({100 * epi.mean() / (epi.mean() + main.mean()):4.1f} % of the item)")
+        for p in range(3):
+            b = 2 + 6 * p
+            seg = [t[:, b] - (t[:, 1] if p == 0 else t[:, b - 6 + 2 + 0] * 0 + t[:, 4 + 6 * (p - 1)]),
+                   t[:, b + 1] - t[:, b], t[:, b + 2] - t[:, b + 1]]
+            nxt = t[:, 2 + 6 * (p + 1)] if p < 2 else t[:, 20]
+            print(f"     pass {p}: [prev tail + column transform + LDS write] {seg[0].mean():6.0f}  [barrier] {seg[1].mean():5.0f}  "
+                  f"[LDS reads + row transform + barrier] {seg[2].mean():5.0f}")
+        print(f"     tail after last pass's second barrier (act / residual / stores): {(t[:, 20] - t[:, 16]).mean():6.0f}")
+finally:
+    shutil.copy("/tmp/lib_keep.so", os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so"))
