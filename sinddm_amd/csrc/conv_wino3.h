@@ -26,14 +26,22 @@
 
 namespace sinddm {
 
-#ifndef W3_PAIR
-#define W3_PAIR 0
-#endif
 constexpr int W3_MT = 5;
 constexpr int W3_NF = 6;                       // horizontal frequencies
 constexpr int W3_Q = 8;                        // 16-byte A groups per (wave, k-step): ceil(5 * 6 / 4)
 constexpr int W3_KS_BYTES = W3_Q * 1024;       // weights of one (i, k-step)
 constexpr int W3_CH_BYTES = 4 * 4 * W3_KS_BYTES;   // ... of one 16-channel chunk (4 waves x 4 k-steps)
+// Order of a (row i, k-step)'s 30 A fragments in the packed image (round 3): 32 four-byte slots per lane = two halves of
+// 16; half MH holds m-tiles MH and 2 + MH (six frequencies each) and frequencies 3 MH .. 3 MH + 2 of m-tile 4, its slot 15
+// is padding.  conv_wino5.h gives a half to each of the two waves of a SIMD (four consecutive 16-byte groups per wave);
+// the kernels that keep a whole row in one wave walk the slots in this order too.  Returns e = m-tile * 6 + frequency, or
+// -1 for padding.
+constexpr int w3_pos_e(int pos) {
+    const int mh = pos >> 4, el = pos & 15;
+    if (el == 15) return -1;
+    const int blk = el / 6, jj = el - blk * 6;
+    return blk < 2 ? (2 * blk + mh) * 6 + jj : 4 * 6 + 3 * mh + jj;
+}
 // floats of the packed F(2x4) image of one conv
 inline long long wino3_packed_floats(int coblks, int nch) { return (long long)coblks * nch * (W3_CH_BYTES / 4); }
 
@@ -231,25 +239,19 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 for (int cc = 0; cc < 6; ++cc) mk[cc] = (ks == 3 && last) ? cmn[cc] : cm[cc];
                 transform(ra, rb, v[(ks + 1) & 1], mk);
                 __builtin_amdgcn_sched_barrier(0);
-                // burst: 30 MFMAs, the A group of four (m-tile, frequency) pairs refilled right behind them
+                // burst: 30 MFMAs in the order of the packed image (w3_pos_e), the A group of four slots refilled right
+                // behind its last MFMA
 #pragma unroll
-                for (int e = 0; e < MT * W3_NF; ++e) {
-                    const int mt = e / W3_NF, j = e - mt * W3_NF;
-                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e >> 2][e & 3], v[ks & 1][j], acc[mt][j], 0, 0, 0);
-#if W3_PAIR
-                    // refills in pairs: four interruptions of the burst instead of eight
-                    if ((e & 7) == 7 || e == MT * W3_NF - 1) {
-                        const int q0 = (e >> 3) * 2;
-                        aq[q0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + q0 * 1024, w_k[ks], 0));
-                        aq[q0 + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + (q0 + 1) * 1024, w_k[ks], 0));
+                for (int pos = 0; pos < 32; ++pos) {
+                    const int e = w3_pos_e(pos);
+                    if (e >= 0) {
+                        const int mt = e / W3_NF, j = e - mt * W3_NF;
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[pos >> 2][pos & 3], v[ks & 1][j], acc[mt][j], 0, 0, 0);
+                    }
+                    if ((pos & 3) == 3) {
+                        aq[pos >> 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + (pos >> 2) * 1024, w_k[ks], 0));
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#else
-                    if ((e & 3) == 3 || e == MT * W3_NF - 1) {
-                        aq[e >> 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + (e >> 2) * 1024, w_k[ks], 0));
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-#endif
                 }
             }
             nb ^= 1;

@@ -60,6 +60,9 @@ __device__ unsigned long long g_w4_seg[8 * 256 * 4 * 32];
 #else
 #define W4_SEG(slot) do {} while (0)
 #endif
+#ifndef W4_PF_BRANCH
+#define W4_PF_BRANCH 1       // 1: the request sits behind a uniform branch on `last chunk`; 0: every chunk issues it, all but
+#endif                       // the last through an empty descriptor (measured: 12 empty loads cost ~600 cycles per chunk)
 #ifndef W4_PF_KS
 #define W4_PF_KS 3            // k-step / slot of a chunk in which the epilogue's pass-0 operands are requested (slot -1: at the
 #define W4_PF_SLOT 58         // top of the epilogue instead).  Late in the LAST chunk: what is queued behind these loads
@@ -205,17 +208,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     unsigned swb[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) swb[s] = lds0 + 4u * (W4_BUF + wi * 4 * W4_PS + swo[s]);
-    auto stage_store = [&](auto N) __attribute__((always_inline)) {
-        constexpr int n = decltype(N)::value;
+    // (ONE write per MFMA slot -- NE = 4 n + e: tools/ubench/mfma_fillers.hip: two LDS writes in a gap are free, four cost 16 cycles)
+    auto stage_store = [&](auto NE) __attribute__((always_inline)) {
+        constexpr int n = decltype(NE)::value >> 2, e = decltype(NE)::value & 3;
         if (W4_ABL & 1) return;
         constexpr int off = (n >> 1) * W4_PS * 4;
         static_assert(off + 12 < 65536, "ds_write_b32 immediate offset");
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned addr = swb[n & 1];               // (locals: asm operands do not capture in a generic lambda)
-            const float val = stg[n & 3][e];
-            asm volatile("ds_write_b32 %0, %1 offset:%c2" ::"v"(addr), "v"(val), "n"(off + 4 * e) : "memory");
-        }
+        const unsigned addr = swb[n & 1];                   // (locals: asm operands do not capture in a generic lambda)
+        const float val = stg[n & 3][e];
+        asm volatile("ds_write_b32 %0, %1 offset:%c2" ::"v"(addr), "v"(val), "n"(off + 4 * e) : "memory");
     };
 
     // ---- weights ----
@@ -223,17 +224,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFF0, 0x00020000);
     const int wlane = lane * 16;
     auto wbase = [&](int cb) -> int { return cb * nch * W3_CH_BYTES + wi * (4 * W3_KS_BYTES); };
-    f32x4 aq[2][W3_Q - 1];                          // ring of two k-steps (groups 0..6; group 7 below)
-    // (group 7 holds only fragments 28, 29: its own 8-byte ring -- as the idle half of a 16-byte load its two dead
-    // registers were reused at once and the waitcnt pass answered the pending load into them with a vmcnt(0) drain)
-    using u32x2_t = __attribute__((ext_vector_type(2))) unsigned;
+    f32x4 aq[2][W3_Q];                              // ring of two k-steps (groups 0-2, 4-6: four fragments)
+    // (groups 3 and 7 of the packed order -- w3_pos_e -- hold three fragments + a padding slot: loaded as 12 bytes into
+    // their own rings; as the idle quarter of a 16-byte load the dead register was reused at once and the waitcnt pass
+    // answered the pending load into it with a vmcnt(0) drain)
     using f32x2 = __attribute__((ext_vector_type(2))) float;
-    f32x2 aq7[2];
+    using f32x3 = __attribute__((ext_vector_type(3))) float;
+    f32x3 aq3[2][2];
     auto load_a = [&](int ring, int q, int soff) __attribute__((always_inline)) {
-        if (q < W3_Q - 1)
+        if ((q & 3) != 3)
             aq[ring][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + q * 1024, soff, 0));
         else
-            aq7[ring] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsw, wlane + q * 1024, soff, 0));
+            aq3[ring][q >> 2] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(rsw, wlane + q * 1024, soff, 0));
     };
     auto chunk_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -455,10 +457,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                 // 60 slots: one MFMA + the non-VALU fillers dealt to its gap
                 w4_static_for<2 * MT * W3_NF>([&](auto S) __attribute__((always_inline)) {
                     constexpr int s = decltype(S)::value;
-                    constexpr int e = s >> 1, h = s & 1;
+                    constexpr int idx = s >> 1, h = s & 1;
+                    constexpr int pos = idx + (idx >= 15 ? 1 : 0);          // slot of the packed order (15 and 31 are padding)
+                    constexpr int e = w3_pos_e(pos);
                     constexpr int mt = e / W3_NF, j = e - mt * W3_NF;
-                    if constexpr ((e >> 2) < W3_Q - 1) w4_mfma<(h * MT + mt) * W3_NF + j>(aq[ks & 1][e >> 2][e & 3], v[ks & 1][j][h]);
-                    else w4_mfma<(h * MT + mt) * W3_NF + j>(aq7[ks & 1][e & 3], v[ks & 1][j][h]);
+                    if constexpr ((pos >> 2 & 3) != 3) w4_mfma<(h * MT + mt) * W3_NF + j>(aq[ks & 1][pos >> 2][pos & 3], v[ks & 1][j][h]);
+                    else w4_mfma<(h * MT + mt) * W3_NF + j>(aq3[ks & 1][pos >> 4][pos & 3], v[ks & 1][j][h]);
                     // raw-patch reads of the next k-step: slots 0..23
                     if constexpr (s < 24 && !(W4_ABL & 4)) {
                         constexpr int hh = s & 1, m = s >> 1, cc = m >> 1, wh = m & 1;
@@ -469,18 +473,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     // raw-tile staging of the next chunk, four 16-byte groups per batch: loaded in k-step 0 / 1, written
                     // to LDS a k-step later
                     if constexpr (ks == 0 && s >= 24 && s < 28) stage_load(s - 24);
-                    if constexpr (ks == 1 && s >= 24 && s < 28) stage_store(std::integral_constant<int, s - 24>{});
-                    if constexpr (ks == 1 && s >= 28 && s < 32) stage_load(s - 28 + 4);
-                    if constexpr (ks == 2 && s >= 50 && s < 54) stage_store(std::integral_constant<int, s - 50 + 4>{});
+                    if constexpr (ks == 1 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4>{});
+                    if constexpr (ks == 1 && s >= 24 && s < 28) stage_load(s - 24 + 4);
+                    if constexpr (ks == 2 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4 + 16>{});
                     // pass-0 operands of the epilogue, requested late in the item's LAST chunk (W4_PF_KS, W4_PF_SLOT: ahead of
                     // their use).  No branch: every chunk issues the twelve loads, all but the last one through an empty
                     // descriptor (no memory traffic; the registers are dead until the epilogue)
-                    if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_pf, rs_pfb);
-                    // weight refills: group q is free behind slot 8 q + 7 (the last group behind slot 59)
-                    if constexpr (!(W4_ABL & 2) && ((s & 7) == 7 || s == 59)) {
-                        constexpr int q = s >> 3;
-                        load_a(ks & 1, q, w_pre[ks]);
+#if W4_PF_BRANCH
+                    if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) {
+                        if (last) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_op, rs_bias);
                     }
+#else
+                    if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_pf, rs_pfb);
+#endif
+                    // weight refills: a group is free behind the MFMAs of its last slot
+                    if constexpr (!(W4_ABL & 2) && h == 1 && ((pos & 3) == 3 || pos == 14 || pos == 30)) load_a(ks & 1, pos >> 2, w_pre[ks]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });

@@ -5,7 +5,7 @@
 // (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
 #include "conv_mfma.h"
 #include "conv_wino.h"
-#include "conv_wino4.h"
+#include "conv_wino5.h"
 #include "internal.h"
 #include "wgrad_wino.h"
 
@@ -1030,7 +1030,7 @@ static int conv3x3_wino(const float* zero, const float* in3, int cin3, const flo
     if (SINDDM_WINO_V3 && wf && mt == 5 &&
         (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count()) {
         c.w3 = wf;
-        if (SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return conv_wino4_launch(c, st);
+        if (SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return SINDDM_WINO_V5 ? conv_wino5_launch(c, st) : conv_wino4_launch(c, st);
         return conv_wino3_launch(c, st);
     }
     return conv_wino_launch(c, mt, st);

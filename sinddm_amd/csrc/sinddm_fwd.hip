@@ -2,7 +2,7 @@
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
 #include "conv_wino.h"
-#include "conv_wino4.h"
+#include "conv_wino5.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -95,7 +95,8 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
         }
     } else if (g.kind == 4) {
         // Winograd F(2x4,3x3) of conv_wino3.h: U = G2 g G4^T, register image [coblk][chunk][i][ks][q][lane][slot];
-        // (q, slot) -> pair e = 4 q + slot = mt * 6 + j (pairs 30, 31 are padding); vertical row 2 stored negated
+        // slot 4 q + slot -> pair e = mt * 6 + j in the order of w3_pos_e (two halves of 15 pairs + a padding slot);
+        // vertical row 2 stored negated
         long long r = j;
         const int slot = (int)(r % 4); r /= 4;
         const int lane = (int)(r % 64); r /= 64;
@@ -104,12 +105,12 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
         const int fi = (int)(r % 4); r /= 4;
         const int ch = (int)(r % g.nch); r /= g.nch;
         const int cb = (int)r;
-        const int e = q8 * 4 + slot;
-        const int mt = e / 6, fj = e - mt * 6;
+        const int e = w3_pos_e(q8 * 4 + slot);
+        const int mt = e < 0 ? 0 : e / 6, fj = e < 0 ? 0 : e - mt * 6;
         const int m = cb * 80 + mt * 16 + (lane & 15);
         const int k = ch * 16 + ks * 4 + (lane >> 4);
         const int M4 = g.transpose ? g.cin : g.cout, K4 = g.transpose ? g.cout : g.cin;
-        if (e < 30 && m < M4 && k < K4) {
+        if (e >= 0 && m < M4 && k < K4) {
             const double G2[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
             const double G4[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
                                      {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
@@ -872,7 +873,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
         if (v3 && b.pk_w1f >= 0) {
             c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
-            rc = v4 ? conv_wino4_launch(c1, st) : conv_wino3_launch(c1, st);
+            rc = v4 ? (SINDDM_WINO_V5 ? conv_wino5_launch(c1, st) : conv_wino4_launch(c1, st)) : conv_wino3_launch(c1, st);
         } else if (wino && b.pk_wc1 >= 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);
@@ -910,7 +911,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
             c2.nch1 = 0;
             if (v3 && b.pk_w2f >= 0) {
                 c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
-                rc = v4 ? conv_wino4_launch(c2, st) : conv_wino3_launch(c2, st);
+                rc = v4 ? (SINDDM_WINO_V5 ? conv_wino5_launch(c2, st) : conv_wino4_launch(c2, st)) : conv_wino3_launch(c2, st);
             } else {
                 c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2;
                 rc = conv_wino_launch(c2, b.mt, st);
@@ -1124,6 +1125,11 @@ int sinddm_debug_w2_phase(unsigned long long* host_dst, int n) {
 #ifdef W4_TIMING
 int sinddm_debug_w4_seg(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_seg), sizeof(unsigned long long) * n);
+}
+#endif
+#ifdef W5_TIMING
+int sinddm_debug_w5_seg(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w5_seg), sizeof(unsigned long long) * n);
 }
 #endif
 #ifdef W2_TIMING

