@@ -5,21 +5,29 @@
 
 Metric (BASELINE.json): diffusion steps/sec at the finest scale + images/sec of a full multi-scale sample.
 One "step" = one reverse diffusion step (p_sample: SinDDMNet forward + fused reverse-step kernel + noise draw) for
-the whole per-GPU batch at the finest pyramid scale.  `value` = sample-steps/s summed over all ranks (weak scaling:
-every rank runs its own independent chains, no data-path collective; the only collective is the all-gather of the
-finished images in the full-sample leg).
+the whole per-GPU batch at the finest pyramid scale.
 
-Default workload at N=1: **C3** (seascape 6-scale pyramid, T=1000, finest scale 411x512, batch 64 -- the largest
-single-GPU configuration of BASELINE.json, its "roofline run").  The C2 record (balloons 5 scales, 186x248, batch 16;
-the round-1 headline) is measured right after it and nested in the same JSON line under "c2", the training step
-(SURVEY 8(d) secondary metric: batch 32 at the C2 finest scale, forward + backward + fused Adam) under "train".
+N = 1 (default): **C3** (seascape 6-scale pyramid, T=1000, finest scale 411x512, batch 64 -- the largest single-GPU
+configuration of BASELINE.json, its "roofline run") is the headline; nested: the C2 record (balloons 5 scales, 186x248,
+batch 16), the training step (SURVEY 8(d) secondary metric) and `strong_scaling_n1`: the two configurations BASELINE
+shards over 8 GPUs run on ONE GPU at their full global batch (C4: 128 chains, C5: 32) and at the 1/8 shard a rank of
+an 8-GPU job gets (16 / 4) -- `shard_efficiency` = pixel-step rate at the shard / rate at the full batch, so the
+predicted 8-GPU speed-up of the sample-batch sharding is 8 x shard_efficiency (the only collective is one all-gather
+of the finished images).
 
-`roofline` describes the dominant kernel (conv_wino_kernel: Winograd F(2x2,3x3) 3x3 convolution on the fp32 matrix
-cores): `achieved` = the FLOPs the matrix pipe has to retire for the algorithmic work of a launch (16/36 of the
-direct-convolution FLOPs 2*9*Cin*Cout per pixel; padded tiles and everything else the kernel does are NOT counted)
-divided by the average launch time measured with HIP events around every launch inside the timed region;
-`frac` = achieved / 157.3 TF/s (<= 1 by construction).  The Winograd saving is reported separately
-(`algorithmic_tflops`, `algorithmic_speedup`).  `cpu_baseline` = the oracle's CPU restatement of the same step.
+N > 1 (one rank per GPU, RCCL): **C4 at the global batch of 128** split over the ranks (strong scaling, what BASELINE's
+"batch=128 sharded 8xMI355X" names); `value` = global batch x steps / max-over-ranks time.  Nested: C5 at global 32
+(strong) and C3 at 64 chains per GPU (weak).  The line carries comm_world_size, per-rank min / max step time and the
+time of the all-gather alone.  --config / --global-batch / --batch override.
+
+`roofline` describes the dominant kernel family (the Winograd F(2x4,3x3) 3x3 convolutions on the fp32 matrix cores:
+conv_wino4_kernel for launches with >= 2 work items per CU, conv_wino3 / conv_wino2 below): `achieved` = the FLOPs the
+matrix pipe has to retire for the algorithmic work of a launch (24/72 of the direct-convolution FLOPs 2*9*Cin*Cout per
+pixel for F(2x4), 16/36 for the F(2x2) small-launch kernel; padded tiles and everything else the kernel does are NOT
+counted) divided by the average launch time measured with HIP events around every launch inside the timed region, on
+the launch stream; `frac` = achieved / 157.3 TF/s (<= 1 by construction).  `traffic` = HBM bytes per launch from the
+PMC passes of the profile named in `traffic_source` (another box), or null.  `cpu_baseline` = the oracle's CPU
+restatement of the same step.
 
 `--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with N ranks
 (one per GPU, RCCL) and fails if the node has fewer than N devices.
@@ -50,8 +58,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3", help="headline workload (C3 = largest 1-GPU config of BASELINE.json)")
-    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the config's per-GPU batch)")
+    ap.add_argument("--config", default=None, help="headline workload (default: C3 at N=1, C4 strong scaling at N>1)")
+    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (weak scaling; default: the config's batch)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total chains over all GPUs (strong scaling; default at N>1: the config's BASELINE batch)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling records (C4 / C5 shards)")
     ap.add_argument("--no-full", action="store_true", help="skip the full multi-scale sample legs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-c2", action="store_true", help="skip the nested C2 record")
@@ -118,6 +129,24 @@ class Ctx:
         self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
         return float(t)
 
+    def min_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.td.all_reduce(t, op=self.td.ReduceOp.MIN)
+        return float(t)
+
+    def gather_shards(self, cur, sizes):
+        """all-gather of uneven batch shards (strong scaling): pad to the largest shard, gather, cut."""
+        if self.world == 1:
+            return cur
+        bmax = max(sizes)
+        pad = cur
+        if cur.shape[0] < bmax:
+            pad = torch.cat([cur, cur.new_zeros((bmax - cur.shape[0],) + tuple(cur.shape[1:]))])
+        out = self.gather(pad, bmax)
+        return torch.cat([out[r * bmax:r * bmax + b] for r, b in enumerate(sizes)])
+
     def gather(self, cur, B):
         if self.world == 1:
             return cur
@@ -137,16 +166,18 @@ def _prof(lib, kind, reset):
 
 
 def _traffic(cfg_name):
-    """HBM bytes per launch of the dominant kernel from the PMC passes (profiles/traffic.json), or None."""
+    """(HBM bytes per launch of the dominant kernel, profile it came from) from the PMC passes recorded in
+    profiles/traffic.json -- measured on the box that ran the profile, not on this one -- or (None, None)."""
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        return t.get(cfg_name, {}).get("conv_bytes_per_launch")
+        return t.get(cfg_name, {}).get("conv_bytes_per_launch"), t.get("source")
     except Exception:
-        return None
+        return None, None
 
 
-def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
-    """Finest-scale reverse steps of one config: the timed region + the roofline of the dominant kernel."""
+def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
+    """Finest-scale reverse steps of one config: the timed region + the roofline of the dominant kernel.  B = chains of
+    THIS rank; global_batch = chains of the whole job (strong scaling: ranks may differ by one)."""
     from sinddm_amd.configs import CONFIGS, build_diffusion
     cfg = CONFIGS[cfg_name]
     torch.manual_seed(seed + ctx.rank)
@@ -173,22 +204,25 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
     dt = time.perf_counter() - t0
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     all_ms, all_n, all_fl, all_ex = _prof(lib, 0, 1)          # every MFMA convolution of the step
-    dt = ctx.max_over_ranks(dt)
+    dt_rank = dt
+    dt = ctx.max_over_ranks(dt_rank)
+    dt_min = ctx.min_over_ranks(dt_rank)
     assert os.environ.get("SINDDM_BENCH_NOFINITE") == "1" or torch.isfinite(img).all()   # (timing-ablation builds)
     px = B * H * W
     avg_launch_ms = dom_ms / max(1, dom_n)
     algorithmic = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_ex / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic = _traffic(cfg_name)
+    traffic, traffic_src = _traffic(cfg_name)
     roofline = {
         "bound": "mfma",
-        "kernel": "conv_wino3_kernel<*> (Winograd F(2x4,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32; 7 launches per step)",
+        "kernel": "conv_wino4_kernel<*> (Winograd F(2x4,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32, one wave per SIMD, "
+                  "two n-tiles per wave; 7 launches per step; launches below 2 work items per CU: conv_wino3 / conv_wino2)",
         "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-        "traffic": traffic,
+        "traffic": traffic, "traffic_source": traffic_src,
         "hbm_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                      if traffic and avg_launch_ms > 0 else None),
-        "flops_counted": "executed MFMA FLOPs: 24/72 of the direct-conv FLOPs of the launch (F(2x4,3x3): 3 multiplies per output instead of 9); padding excluded",
+        "flops_counted": "executed MFMA FLOPs as recorded per launch: 24/72 of the direct-conv FLOPs for the F(2x4,3x3) kernels (3 multiplies per output instead of 9), 16/36 for F(2x2) small launches; padding excluded",
         "executed_flops_per_launch": round(dom_ex / max(1, dom_n)),
         "algorithmic_flops_per_launch": round(dom_fl / max(1, dom_n)),
         "algorithmic_tflops": round(algorithmic, 2), "algorithmic_speedup": round(algorithmic / executed, 3) if executed > 0 else None,
@@ -201,9 +235,13 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed):
                            "launches": int(all_n), "share_of_step": round(all_ms / (dt * 1e3), 4)},
         "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * steps / dt / 1e12, 2),
     }
-    rec = {"workload": f"{cfg_name}: {n_scales}-scale pyramid, T={cfg['T']}, finest scale {H}x{W}, batch {B} per GPU, dim=160",
-           "value": round(ctx.world * B * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4),
-           "steps_per_sec_per_gpu": round(steps / dt, 4), "batch_per_gpu": B, "finest_hw": [H, W], "scale": s,
+    G = global_batch if global_batch is not None else ctx.world * B
+    rec = {"workload": f"{cfg_name}: {n_scales}-scale pyramid, T={cfg['T']}, finest scale {H}x{W}, "
+                       + (f"global batch {G} over {ctx.world} GPU(s)" if global_batch is not None else f"batch {B} per GPU") + ", dim=160",
+           "value": round(G * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4),
+           "ms_per_step_rank_min_max": [round(dt_min / steps * 1e3, 4), round(dt / steps * 1e3, 4)],
+           "pixel_steps_per_sec": round(G * H * W * steps / dt, 1),
+           "steps_per_sec_per_gpu": round(steps / dt, 4), "batch_per_gpu": B, "global_batch": G, "finest_hw": [H, W], "scale": s,
            "roofline": roofline}
     return rec, (net, d, cfg, H, W, s, total_t)
 
@@ -244,9 +282,11 @@ def elementwise_leg(d, B, H, W, s, total_t, dev):
     return res
 
 
-def full_sample_leg(ctx, d, cfg, B):
-    """One FULL multi-scale sample (all scales, upsample + re-noise between them, all-gather of the results)."""
+def full_sample_leg(ctx, d, cfg, B, sizes=None):
+    """One FULL multi-scale sample (all scales, upsample + re-noise between them, all-gather of the results).  B = chains
+    of this rank; sizes = every rank's chains when they differ (strong scaling)."""
     n_scales = len(cfg["sizes"])
+    total = sum(sizes) if sizes else ctx.world * B
     mul = cfg.get("scale_mul", (1, 1))
     ctx.barrier()
     t0 = time.perf_counter()
@@ -254,16 +294,21 @@ def full_sample_leg(ctx, d, cfg, B):
     for si in range(1, n_scales):
         cur = d.sample_via_scale(B, cur, s=si, scale_mul=mul, custom_sample=True, custom_img_size_idx=si,
                                  custom_t=d.num_timesteps_ideal[si])
-    cur = ctx.gather(cur, B)
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    cur = ctx.gather_shards(cur, sizes) if sizes else ctx.gather(cur, B)
+    torch.cuda.synchronize()
+    tg = ctx.max_over_ranks(time.perf_counter() - tg)
     ctx.barrier()
     ft = ctx.max_over_ranks(time.perf_counter() - t0)
     pix_steps = 0
     for si in range(n_scales):
         h, w = d.target_size(si, mul, True, si)
         pix_steps += h * w * d.num_timesteps_ideal[si]
-    return {"imgs_per_sec": round(ctx.world * B / ft, 4), "seconds": round(ft, 3), "images": ctx.world * B,
+    return {"imgs_per_sec": round(total / ft, 4), "seconds": round(ft, 3), "images": total,
+            "all_gather_seconds": round(tg, 6) if ctx.world > 1 else 0.0,
             "net_evals_per_image": sum(d.num_timesteps_ideal),
-            "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * B * ctx.world / ft / 1e12, 2),
+            "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * total / ft / 1e12, 2),
             "finite": bool(torch.isfinite(cur).all())}
 
 
@@ -346,22 +391,69 @@ def main():
     from sinddm_amd.configs import CONFIGS
     lib = _lib.load()
 
+    from sinddm_amd.dist import shard_sizes
+
     def per_gpu_batch(name):
         c = CONFIGS[name]
         return c["batch"] if name in ("C1", "C2", "C3") else max(1, c["batch"] // 8)   # C4/C5 are 8-GPU configs
 
-    B = args.batch or per_gpu_batch(args.config)
-    head, (net, d, cfg, H, W, s, total_t) = steps_leg(ctx, lib, args.config, B, args.steps, args.warmup, args.seed)
+    def brief(rec):
+        return {k: rec[k] for k in ("workload", "value", "ms_per_step", "ms_per_step_rank_min_max", "pixel_steps_per_sec",
+                                    "batch_per_gpu", "global_batch")} | {"frac": rec["roofline"]["frac"]}
+
+    strong = ctx.world > 1 and args.batch is None
+    cfg_name = args.config or ("C4" if strong else "C3")
+    if strong:
+        G = args.global_batch or CONFIGS[cfg_name]["batch"]
+        sizes = shard_sizes(G, ctx.world)
+        if min(sizes) < 1:
+            raise SystemExit(f"bench.py: global batch {G} leaves a rank of {ctx.world} without a chain (use --global-batch / --batch)")
+        B = sizes[ctx.rank]
+    else:
+        G, sizes = None, None
+        B = args.batch or per_gpu_batch(cfg_name)
+    head, (net, d, cfg, H, W, s, total_t) = steps_leg(ctx, lib, cfg_name, B, args.steps, args.warmup, args.seed, G)
     head["elementwise"] = elementwise_leg(d, B, H, W, s, total_t, ctx.dev)
-    full = None if args.no_full else full_sample_leg(ctx, d, cfg, B)
+    full = None if args.no_full else full_sample_leg(ctx, d, cfg, B, sizes)
     cpu = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu:
         cpu = cpu_leg(cfg, len(cfg["sizes"]), B, H, W, s, total_t)
     del net, d
     torch.cuda.empty_cache()
 
+    nested = {}
+    if ctx.world == 1 and not args.no_strong:
+        # what an 8-GPU job of BASELINE's sharded configs does, measured on one GPU: the full global batch and the 1/8 shard
+        sn = {}
+        for name in ("C4", "C5"):
+            Gn = CONFIGS[name]["batch"]
+            rf, st_f = steps_leg(ctx, lib, name, Gn, 5, 2, args.seed)
+            del st_f
+            torch.cuda.empty_cache()
+            rs, st_s = steps_leg(ctx, lib, name, max(1, Gn // 8), 10, 2, args.seed)
+            del st_s
+            torch.cuda.empty_cache()
+            eff = rs["pixel_steps_per_sec"] / rf["pixel_steps_per_sec"]
+            sn[name] = {"full_batch_on_one_gpu": brief(rf), "shard_of_8": brief(rs), "shard_efficiency": round(eff, 4),
+                        "predicted_speedup_8_gpus": round(8 * eff, 3)}
+        sn["note"] = ("one GPU only: the 1 -> 8 GPU curve itself is not measured here; the sample-batch sharding has no "
+                      "data-path collective, so speed-up(8) = 8 x shard_efficiency minus one all-gather of the images")
+        nested["strong_scaling_n1"] = sn
+    if ctx.world > 1 and strong and not args.no_strong:
+        other = "C5" if cfg_name != "C5" else "C4"
+        Go = CONFIGS[other]["batch"]
+        so = shard_sizes(Go, ctx.world)
+        ro, st_o = steps_leg(ctx, lib, other, so[ctx.rank], 10, 2, args.seed, Go)
+        nested[other.lower() + "_strong"] = brief(ro) | {"scaling": "strong"}
+        del st_o
+        torch.cuda.empty_cache()
+        rw, st_w = steps_leg(ctx, lib, "C3", per_gpu_batch("C3"), 4, 1, args.seed)
+        nested["c3_weak"] = brief(rw) | {"scaling": "weak"}
+        del st_w
+        torch.cuda.empty_cache()
+
     c2 = None
-    if args.config != "C2" and not args.no_c2:
+    if cfg_name != "C2" and not args.no_c2:
         c2, (net2, d2, cfg2, H2, W2, s2, tt2) = steps_leg(ctx, lib, "C2", per_gpu_batch("C2"), 20, 3, args.seed)
         c2["elementwise"] = elementwise_leg(d2, per_gpu_batch("C2"), H2, W2, s2, tt2, ctx.dev)
         if not args.no_full:
@@ -378,14 +470,17 @@ def main():
             "metric": "diffusion steps/sec (finest scale) + imgs/sec full multi-scale sample, 1/2/4/8 GPU",
             "value": head["value"], "unit": "sample-steps/s (finest scale, batch x steps/s, all GPUs)",
             "n_gpus": ctx.world, "comm_world_size": ctx.comm_world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "steps_per_sec_per_gpu": head["steps_per_sec_per_gpu"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": head["ms_per_step"], "ms_per_step_rank_min_max": head["ms_per_step_rank_min_max"],
+            "steps_per_sec_per_gpu": head["steps_per_sec_per_gpu"],
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (closed-form weights of the dim=160 architecture, torch.randn noise/images)",
-            "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": B * ctx.world,
-                       "finest_hw": [H, W], "scale": s, "parallelism": f"independent chains x{ctx.world}"},
+            "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": head["global_batch"],
+                       "shards": sizes, "finest_hw": [H, W], "scale": s,
+                       "parallelism": f"independent chains over {ctx.world} GPU(s), one all-gather of the images"},
             "full_sample": full, "roofline": head["roofline"], "elementwise": head["elementwise"],
             "cpu_baseline": cpu, "c2": c2, "train": train,
         }
+        line.update(nested)
         print(json.dumps(line), flush=True)
     if ctx.world > 1:
         ctx.td.destroy_process_group()

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
 }
 
 #ifndef SINDDM_V4_MIN_ITEMS_PER_CU   // launches with at least this many (8x32 tile, 80-channel block) items per CU take conv_wino4.h
-#define SINDDM_V4_MIN_ITEMS_PER_CU 4
+#define SINDDM_V4_MIN_ITEMS_PER_CU 2
 #endif
 
 inline bool conv_wino4_applies(int B, int H, int W, int coblks) {

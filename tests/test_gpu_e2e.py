@@ -286,15 +286,43 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     env.update(SINDDM_BENCH_BACKEND="gloo", SINDDM_BENCH_ONE_DEVICE="1")
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3",
-                        "--warmup", "1", "--no-cpu", "--no-c2", "--no-train"], capture_output=True, text=True, env=env,
-                       timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--config", "C1", "--batch", "1",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--no-c2", "--no-train"], capture_output=True,
+                       text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["comm_world_size"] == 2
+    assert line["n_gpus"] == 2 and line["comm_world_size"] == 2 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
     assert line["full_sample"]["images"] == 2 * line["config"]["batch_per_gpu"] and line["full_sample"]["finite"]
     assert 0 < line["roofline"]["frac"] <= 1.0
+
+
+def test_bench_strong_scaling_c4_two_ranks():
+    """The N > 1 default of bench.py: C4 at a FIXED global batch split over the ranks (128 -> 16 per GPU on
+    8 GPUs).  Two ranks on the one device (gloo for the collectives), global batch 9 -> shards [5, 4]: value counts
+    the global batch, the full sample gathers 9 images through the padded all-gather, per-rank min / max times and the
+    all-gather time are reported."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(SINDDM_BENCH_BACKEND="gloo", SINDDM_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--global-batch", "9", "--steps", "2",
+                        "--warmup", "1", "--no-cpu", "--no-c2", "--no-train", "--no-strong"], capture_output=True,
+                       text=True, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["comm_world_size"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["workload"].startswith("C4") and line["config"]["shards"] == [5, 4]
+    assert line["config"]["global_batch"] == 9 and line["config"]["finest_hw"] == [198, 252]
+    assert abs(line["value"] - 9 * 2 / (line["ms_per_step"] * 2e-3)) / line["value"] < 1e-3
+    lo, hi = line["ms_per_step_rank_min_max"]
+    assert 0 < lo <= hi == line["ms_per_step"]
+    fs = line["full_sample"]
+    assert fs["images"] == 9 and fs["finite"] and fs["all_gather_seconds"] > 0
 
 
 def test_integration_option_b_snippet():
