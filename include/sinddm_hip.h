@@ -8,7 +8,8 @@
  * Conventions
  *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
  *     (PyTorch-ROCm tensors) unless marked "host"; the library never allocates or
- *     frees device memory and keeps no mutable global state.  It reads no
+ *     frees device memory and keeps no mutable global state that a call's result depends
+ *     on (the only cached value is the CU count per device id, queried once).  It reads no
  *     environment variable: kernel selection is fixed at compile time.  (The opt-in measurement
  *     hooks live in sinddm_hip_debug.h and are not part of this contract.)
  *   - all tensors are fp32, NCHW, contiguous.  Timesteps are int64.

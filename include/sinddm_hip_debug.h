@@ -20,11 +20,11 @@ extern "C" {
  * not thread-safe; off by default.  No reference counterpart (the reference has no profiling). */
 int sinddm_prof_begin(void);
 int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total);
-/* same, plus the FLOPs the matrix cores actually executed (Winograd F(2x2,3x3) launches execute 16/36
- * of their algorithmic FLOPs) */
+/* same, plus the FLOPs the matrix cores actually executed (Winograd F(2x4,3x3) launches -- conv_wino3/4/5 -- execute
+ * 24/72 of their algorithmic FLOPs, F(2x2,3x3) ones -- conv_wino2 -- 16/36) */
 int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
                      double* conv_exec_flops_total);
-/* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino_kernel), 2 = 1x1 convs,
+/* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino2/3/4/5_kernel), 2 = 1x1 convs,
  * 3 = direct 3x3 (conv_mfma_dma_kernel).  reset = 0 keeps the records so that several kinds can be queried. */
 int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total,
                      double* exec_flops_total, int reset);

@@ -58,10 +58,17 @@ def needs_build() -> bool:
 
 
 def verify() -> None:
-    """Raise if the library is missing or was built from other sources than the ones beside it."""
+    """Raise if the library is missing or was built from other sources than the ones beside it.  A deployment that ships
+    the library without csrc/ (nothing to compare with) is accepted as it is."""
     if not os.path.exists(LIB):
         raise RuntimeError(f"{LIB} is missing: run `python -m sinddm_amd.build`")
-    if stamp() != source_hash():
+    if not os.path.isdir(CSRC) or not os.path.isdir(INCLUDE):
+        return
+    try:
+        current = source_hash()
+    except OSError as e:
+        raise RuntimeError(f"cannot read the sources beside {LIB}: {e}") from None
+    if stamp() != current:
         raise RuntimeError(f"{LIB} is stale (csrc/ or include/ changed since it was built): run `python -m sinddm_amd.build`")
 
 

@@ -392,8 +392,11 @@ inline int device_cu_count() {
 
 inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
 #if SINDDM_WINO_V2
-    // (the second-generation kernel stages a wave's four channel planes of a chunk through one descriptor)
-    if (a_in.Cin % 4 == 0) return conv_wino2_launch(a_in, mt, st);
+    // (the second-generation kernel stages a wave's four channel planes of a chunk through one descriptor; the packed
+    // Winograd image has ITS layout, so the first-generation kernel below must not see it: callers route convs with
+    // C_in % 4 != 0 -- dim = 10, 20, 28 ... -- to the direct kernel)
+    if (a_in.Cin % 4 != 0) return SINDDM_E_BADSHAPE;
+    return conv_wino2_launch(a_in, mt, st);
 #endif
     ConvArgs a = a_in;
     const int ntr = wino_ntr();

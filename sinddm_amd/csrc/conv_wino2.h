@@ -646,14 +646,18 @@ inline void conv_wino2_launch_t(const ConvArgs& a, unsigned grid, int ipx, int w
     else conv_wino2_launch_e<MT, MTP, 2>(a, grid, ipx, wpx, st);                         // + 4-byte stores of the last odd column
 }
 
+// CU count of the CURRENT device (kernel selection thresholds and persistent grid sizes).  Cached per device id: the
+// only mutable state of the library besides the debug profiler -- idempotent, and a race on it writes the same value.
 inline int wino2_cu_count() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev];
+    if (v <= 0) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-        return v;
-    }();
-    return n;
+        cache[dev] = v;
+    }
+    return v;
 }
 
 inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {

@@ -1065,7 +1065,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
             if (rc) return rc;
         }
         // dU = dgrad_conv2(dO) * GELU'(u)
-        if (wino_enabled())
+        if (wino_enabled() && b.cout % 4 == 0)        // (K of both data-gradient convs = cout; % 4: see conv_wino_launch)
             rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], k.wdg2f[l] >= 0 ? packed_bwd + k.wdg2f[l] : nullptr, tb.u[l], 2,
                               dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
         else
@@ -1075,7 +1075,7 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         // conv1 weight grads, dH = dgrad_conv1(dU)
         rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
         if (rc) return rc;
-        if (wino_enabled() && k.wdg1[l] >= 0)
+        if (wino_enabled() && k.wdg1[l] >= 0 && b.cout % 4 == 0)
             rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], k.wdg1f[l] >= 0 ? packed_bwd + k.wdg1f[l] : nullptr, nullptr, 0,
                               dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
         else

@@ -874,7 +874,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         if (v3 && b.pk_w1f >= 0) {
             c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
             rc = v4 ? (SINDDM_WINO_V5 ? conv_wino5_launch(c1, st) : conv_wino4_launch(c1, st)) : conv_wino3_launch(c1, st);
-        } else if (wino && b.pk_wc1 >= 0) {
+        } else if (wino && b.pk_wc1 >= 0 && b.cin % 4 == 0) {
             c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
             rc = conv_wino_launch(c1, b.mt, st);
         } else if (b.cin == 3 && c3) {
@@ -895,7 +895,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         c2.in = gbuf; c2.out = obuf;
         c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;
         c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
-        if (wino) {
+        if (wino && b.cout % 4 == 0) {       // (C_in of conv2 = cout; % 4: see conv_wino_launch)
             // Winograd 3x3; a 1x1 residual projection runs first on the direct kernel and is added as `resid`
             if (b.nchr > 0) {
                 ConvArgs r1{};

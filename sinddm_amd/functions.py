@@ -182,3 +182,16 @@ def match_histograms(image: np.ndarray, reference: np.ndarray, channel_axis: int
         interp = np.interp(src_q, tmpl_q, tmpl_values)
         out[..., ch] = interp[lookup].reshape(src.shape)
     return out
+
+
+def thresholded_grad(grad, quantile=0.8):
+    """Soft-thresholded guidance gradient + the mask of the positions that survive (reference SinDDM/functions.py:52-67):
+    per sample the pixel-wise gradient energy ||grad||_2 over channels is reduced by its `quantile` (nearest) and clamped
+    at 0; the direction of the gradient is kept.  Returns (sparse_grad (B,C,H,W), mask (B,1,H,W) bool)."""
+    energy = torch.norm(grad, dim=1)                                                   # (B,H,W)
+    q = torch.quantile(energy.reshape(energy.shape[0], -1), q=quantile, dim=1, interpolation='nearest')[:, None, None]
+    excess = energy - q
+    mask = (excess > 0)[:, None, :, :]
+    unit = grad / energy[:, None, :, :]
+    unit[torch.isnan(unit)] = 0
+    return torch.clamp(excess, min=0)[:, None, :, :] * unit, mask

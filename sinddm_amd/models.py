@@ -313,9 +313,10 @@ class MultiScaleGaussianDiffusion(nn.Module):
         self.reblurring = reblurring
         self.img_prev_upsample = None
 
-        # guided-sampling state of the reference (models.py:193-220).  The guidance branches are
-        # application features outside the hot path; the attributes are kept so callers that set
-        # them keep working, and p_mean_variance raises if guidance is switched on.
+        # guided-sampling state of the reference (models.py:193-220).  CLIP itself (clip/, text2live_util/) is outside
+        # the hot-path build; the guidance BRANCH of p_mean_variance (models.py:367-431) is implemented against the
+        # interface the reference uses: `clip_model` is any object with zero_grad() and a differentiable
+        # calculate_clip_loss(image in [0,1], text_embedds) -> scalar (stock PyTorch-ROCm autograd).
         self.clip_guided_sampling = False
         self.guidance_sub_iters = None
         self.stop_guidance = None
@@ -501,22 +502,70 @@ class MultiScaleGaussianDiffusion(nn.Module):
         self._roi_cache = {"key": key, "w": w.contiguous(), "c": c.contiguous()}
         return self._roi_cache["w"], self._roi_cache["c"]
 
-    def p_mean_variance(self, x, t, s, clip_denoised: bool):               # models.py:354-447 (normal + ROI branch)
-        if self.clip_guided_sampling:
-            raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
-        eps = self._eps(x, t, int(t[0]), s)
-        x_recon, x_t_mix = self.predict_start_from_noise(x, t=t, s=s, noise=eps)
-        if self.roi_guided_sampling and (s < self.n_scales - 1):           # models.py:430-431
-            x_recon = self.roi_patch_modification(x_recon, scale=s)
-        if int(s) > 0 and t[0] > 0 and self.reblurring:
-            g = extract(self.gammas[s - 1].reshape(-1).clamp(0, 0.55), t - 1, x_recon.shape)
-            x_tm1_mix = g * self.img_prev_upsample + (1 - g) * x_recon
-        else:
-            x_tm1_mix = x_recon
+    def _clip_guidance(self, x_recon, t0: int, s: int, clip_denoised: bool):
+        """The CLIP-guidance block of p_mean_variance (models.py:367-421): the score's gradient is taken with respect to
+        x_recon itself (a leaf -- nothing flows back through the network), soft-thresholded into a mask at the first
+        call, normalised to the image's norm inside the mask and added; changes of the previous step are blended in
+        with `llambda`.  Runs on stock PyTorch autograd: `clip_model` is external (see __init__)."""
+        from .functions import thresholded_grad
         if clip_denoised:
-            x_tm1_mix = x_tm1_mix.clamp(-1., 1.)
-            x_t_mix = x_tm1_mix if ((not self.reblurring) or s == 0) else x_t_mix.clamp(-1., 1.)
-        return self.q_posterior(x_start=x_tm1_mix, x_t_mix=x_t_mix, x_t=x, t=t, s=s)
+            x_recon = x_recon.clamp(-1., 1.)
+        if self.clip_mask is not None:
+            x_recon = x_recon * (1 - self.clip_mask) + (
+                (1 - self.llambda) * self.x_recon_prev + self.llambda * x_recon) * self.clip_mask
+        x_recon = x_recon.detach().requires_grad_(True)
+        emb = self.text_embedds_hr if s > 0 else self.text_embedds_lr
+        with torch.enable_grad():
+            for _ in range(self.guidance_sub_iters[s]):
+                self.clip_model.zero_grad()
+                score = -self.clip_model.calculate_clip_loss((x_recon + 1) * 0.5, emb)
+                clip_grad = torch.autograd.grad(score, x_recon, create_graph=False)[0]
+                if self.clip_mask is None:
+                    clip_grad, clip_mask = thresholded_grad(grad=clip_grad, quantile=self.quantile)
+                    self.clip_mask = clip_mask.float()
+                with torch.no_grad():
+                    division_norm = torch.linalg.vector_norm(x_recon * self.clip_mask, dim=(1, 2, 3), keepdim=True) / \
+                        torch.linalg.vector_norm(clip_grad * self.clip_mask, dim=(1, 2, 3), keepdim=True)
+                    x_recon += self.clip_strength * division_norm * clip_grad * self.clip_mask
+                    x_recon.clamp_(-1., 1.)
+                self.clip_score.append(score.detach().cpu())
+        self.x_recon_prev = x_recon.detach()
+        return self.x_recon_prev.clone()
+
+    def _clip_active(self, t0: int, s: int) -> bool:                        # the condition of models.py:368
+        return bool(self.clip_guided_sampling and (self.stop_guidance <= t0 or s < self.n_scales - 1)
+                    and self.guidance_sub_iters[s] > 0)
+
+    def p_mean_variance(self, x, t, s, clip_denoised: bool):               # models.py:354-447
+        with torch.no_grad():
+            eps = self._eps(x, t, int(t[0]), s)
+            x_recon, x_t_mix = self.predict_start_from_noise(x, t=t, s=s, noise=eps)
+        if self._clip_active(int(t[0]), int(s)):                            # models.py:367-421
+            x_recon = self._clip_guidance(x_recon, int(t[0]), int(s), clip_denoised)
+        elif self.roi_guided_sampling and (s < self.n_scales - 1):         # models.py:430-431
+            x_recon = self.roi_patch_modification(x_recon, scale=s)
+        with torch.no_grad():
+            if int(s) > 0 and t[0] > 0 and self.reblurring:
+                g = extract(self.gammas[s - 1].reshape(-1).clamp(0, 0.55), t - 1, x_recon.shape)
+                x_tm1_mix = g * self.img_prev_upsample + (1 - g) * x_recon
+            else:
+                x_tm1_mix = x_recon
+            if clip_denoised:
+                x_tm1_mix = x_tm1_mix.clamp(-1., 1.)
+                x_t_mix = x_tm1_mix if ((not self.reblurring) or s == 0) else x_t_mix.clamp(-1., 1.)
+            return self.q_posterior(x_start=x_tm1_mix, x_t_mix=x_t_mix, x_t=x, t=t, s=s)
+
+    def _p_sample_guided(self, x, t_host: int, s: int, clip_denoised: bool, repeat_noise: bool):
+        """p_sample (models.py:449-459) through p_mean_variance in eager torch ops: the path of CLIP-guided steps (the
+        fused reverse-step kernel has no place for an external autograd call between x_recon and the posterior)."""
+        t = torch.full((x.shape[0],), int(t_host), device=x.device, dtype=torch.long)
+        mean, _, logvar = self.p_mean_variance(x=x, t=t, s=s, clip_denoised=clip_denoised)
+        if repeat_noise:
+            z = noise_like(x.shape, x.device, True)
+        else:
+            z = self._draw("step", x.shape, s, t_host, x.device)
+        nonzero = 0.0 if t_host == 0 else 1.0
+        return mean + nonzero * (0.5 * logvar).exp() * z
 
     # ---- hot path -----------------------------------------------------------------------------
     def _coef_table(self, s: int, clip_denoised: bool = True):
@@ -544,7 +593,8 @@ class MultiScaleGaussianDiffusion(nn.Module):
         s = int(s)
         fast = (self.noise_fn is None and isinstance(self.denoise_fn, SinDDMNet) and not self.save_interm
                 and not self.clip_guided_sampling and not (self.roi_guided_sampling and s < self.n_scales - 1)
-                and len(t_seq) > 0 and img.is_cuda)
+                and len(t_seq) > 0 and img.is_cuda and img.dtype == torch.float32 and img.dim() == 4
+                and img.shape[1] == self.channels == 3)
         if not fast:
             for i in t_seq:
                 img = self._p_sample_host_t(img, i, s)
@@ -565,10 +615,16 @@ class MultiScaleGaussianDiffusion(nn.Module):
             xt = self.img_prev_upsample
             if xt is None:
                 raise _lib.SinddmError("img_prev_upsample is not set (call sample_via_scale / p_sample_via_scale_loop)")
+            if xt.shape != x.shape or xt.dtype != x.dtype or xt.device != x.device:
+                # (the library takes raw pointers: a mismatching x-tilde would be read out of bounds)
+                raise _lib.SinddmError(f"img_prev_upsample {tuple(xt.shape)} {xt.dtype} {xt.device} does not match the "
+                                       f"running sample {tuple(x.shape)} {x.dtype} {x.device}")
             xt = xt.contiguous()
         packed = net.packed_weights()
         ws = _workspace(x.device, lib.sinddm_workspace_bytes(net.dim, B, H, W))
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))      # from torch's (seedable) CPU generator
+        # the step noise is keyed on a 62-bit seed drawn from torch's CPU generator: torch.manual_seed() reproduces a
+        # sample, seeding only the CUDA generator (torch.cuda.manual_seed) does not
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
         in_alt = C.c_int(0)
         _lib.check(lib.sinddm_sample_chain(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
@@ -586,6 +642,8 @@ class MultiScaleGaussianDiffusion(nn.Module):
     def _p_sample_host_t(self, x: torch.Tensor, t: int, s: int, clip_denoised: bool = True,
                          repeat_noise: bool = False) -> torch.Tensor:
         """One reverse step with the timestep known on the host: net forward + ONE fused kernel."""
+        if self.clip_guided_sampling:
+            return self._p_sample_guided(x.contiguous(), int(t), int(s), clip_denoised, repeat_noise)
         lib = _lib.load()
         x = x.contiguous()
         eps = self._eps(x, None, t, s)
@@ -614,8 +672,6 @@ class MultiScaleGaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def p_sample(self, x, t, s, clip_denoised=True, repeat_noise=False):   # models.py:449-459
-        if self.clip_guided_sampling:
-            raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
         t_host = int(t[0]) if isinstance(t, torch.Tensor) else int(t)      # the reference also reads t[0] (:331,:434)
         return self._p_sample_host_t(x, t_host, int(s), clip_denoised, repeat_noise)
 
@@ -656,8 +712,13 @@ class MultiScaleGaussianDiffusion(nn.Module):
         noise = self._draw("renoise", img.shape, s, 0, img.device)
         img = self._q_sample_impl(img, None, total_t, noise)                # models.py:518
         self._dump_interm(img, s, f'noisy_input_s_{s}.png')
-        if self.clip_mask is not None:
-            raise NotImplementedError("CLIP guided sampling is outside the MI355X hot-path build")
+        if self.clip_mask is not None:                                      # models.py:528-535
+            if s > 0:
+                mul_size = [int(self.image_sizes[s][0] * self.scale_mul[0]), int(self.image_sizes[s][1] * self.scale_mul[1])]
+                self.clip_mask = F.interpolate(self.clip_mask, size=mul_size, mode='bilinear')
+                self.x_recon_prev = F.interpolate(self.x_recon_prev, size=mul_size, mode='bilinear')
+            else:                                                           # a mask created at scale 0 is too noisy
+                self.clip_mask = None
         if self.sample_limited_t and s < (self.n_scales - 1):
             t_min = self.num_timesteps_ideal[s + 1]
         else:

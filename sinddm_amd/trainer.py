@@ -421,9 +421,43 @@ class MultiscaleTrainer(object):
         finally:
             em.roi_guided_sampling = False
 
-    # ---- CLIP-driven modes of the reference (need CLIP autograd: out of the hot-path scope) ----
-    def clip_sampling(self, *a, **k):
-        raise NotImplementedError('CLIP guided sampling is outside the MI355X hot-path build')
+    # ---- CLIP-driven modes of the reference.  CLIP itself (clip/, text2live_util/) is not part of this build; the
+    # driver takes any `clip_model` with the interface the reference uses: get_text_embedding(text, template=...),
+    # zero_grad(), calculate_clip_loss(image in [0,1], embedding) (differentiable), cfg["n_aug"] ----
+    def clip_sampling(self, clip_model, text_input, strength, sample_batch_size, custom_t_list=None,
+                      guidance_sub_iters=None, quantile=0.8, stop_guidance=None, save_unbatched=False, scale_mul=(1, 1),
+                      llambda=0, start_noise=True, image_name='', templates=('hr', 'lr')):   # trainer.py:363-410
+        em = self.ema_model
+        if guidance_sub_iters is None:
+            guidance_sub_iters = [*reversed(range(self.n_scales))]
+        em.clip_strength = strength
+        em.clip_text = text_input
+        em.text_embedds_hr = clip_model.get_text_embedding(text_input, template=templates[0])
+        em.text_embedds_lr = clip_model.get_text_embedding(text_input, template=templates[1])
+        em.clip_guided_sampling = True
+        em.guidance_sub_iters = guidance_sub_iters
+        em.quantile = quantile
+        em.stop_guidance = stop_guidance
+        em.clip_model = clip_model
+        em.clip_score = []
+        em.llambda = llambda
+        em.clip_mask = None
+        em.x_recon_prev = None
+        n_aug = getattr(clip_model, "cfg", {}).get("n_aug", 0)
+        desc = (f"clip_{text_input.replace(' ', '_')}_n_aug{n_aug}_str_{strength}_gsi_" + '_'.join(str(e) for e in guidance_sub_iters)
+                + f'_ff{1 - quantile}' + f'_{str(datetime.datetime.now()).replace(":", "_")}')
+        try:
+            if not start_noise:                                             # clip_style_trans: start from the last two scales
+                return self.sample_scales(scale_mul=scale_mul, custom_sample=True,
+                                          custom_scales=[self.n_scales - 2, self.n_scales - 1],
+                                          custom_image_size_idxs=[self.n_scales - 2, self.n_scales - 1],
+                                          image_name=image_name, batch_size=sample_batch_size, custom_t_list=custom_t_list,
+                                          desc=desc, save_unbatched=save_unbatched, start_noise=start_noise)
+            return self.sample_scales(scale_mul=scale_mul, custom_sample=False, image_name='', batch_size=sample_batch_size,
+                                      custom_t_list=custom_t_list, desc=desc, save_unbatched=save_unbatched,
+                                      start_noise=start_noise)
+        finally:
+            em.clip_guided_sampling = False
 
     def clip_roi_sampling(self, *a, **k):
         raise NotImplementedError('CLIP ROI sampling is outside the MI355X hot-path build')

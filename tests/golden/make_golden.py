@@ -24,6 +24,8 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
   g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
   g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
+  g15_clip_guided.npz CLIP-guided p_sample steps (models.py:367-431) with a SYNTHETIC differentiable score in place of
+                     CLIP (clip/ is out of scope): mask creation, sub-iterations, lambda blending across steps, dim=32
   g13_roi_i2i.npz    ROI-guided p_sample steps (roi_patch_modification) and an image2image (style-transfer path,
                      no mask / no histogram matching: scikit-image is absent) chain, dim=32, hash noise
 """
@@ -590,7 +592,65 @@ def g13(workdir):
     save("g13_roi_i2i.npz", **out)
 
 
+class SyntheticScore:
+    """Stands in for clip.ClipExtractor: `calculate_clip_loss(img in [0,1], embedding)` -> scalar, differentiable.
+    The 'embedding' is an image; the loss is a weighted squared distance after a smooth nonlinearity."""
+
+    def zero_grad(self):
+        pass
+
+    def calculate_clip_loss(self, x, emb):
+        w = 0.5 + closed_form_tensor(tuple(x.shape), phase=1.3, amp=0.5, freq=0.173).abs()
+        return (w * (torch.tanh(2.0 * x) - emb) ** 2).mean() * 3.0
+
+
+def g15(workdir):
+    """The guidance branch of p_mean_variance through the reference (models.py:367-431)."""
+    cfg = CONFIGS["C1"]
+    dst, fname, sizes, losses, sf, n = run_create_img_scales(cfg, os.path.join(workdir, "G15"))
+    d = make_diffusion(ref_net(32), sizes, losses, sf, n, cfg["T"])
+    res = str(d.results_folder)
+    d.clip_guided_sampling = True
+    d.clip_model = SyntheticScore()
+    d.guidance_sub_iters = [1, 2, 0]
+    d.stop_guidance = 3
+    d.quantile = 0.8
+    d.clip_strength = 0.3
+    d.llambda = 0.2
+    out = {}
+    o_noise_like = rm.noise_like
+    try:
+        for s, (H, W), ts in ((0, (48, 64), (17, 16)), (1, (67, 90), (17, 16, 0))):
+            d.clip_mask = None
+            d.x_recon_prev = None
+            d.clip_score = []
+            d.text_embedds_hr = closed_form_tensor((2, 3, H, W), phase=0.9, amp=0.4, freq=0.131) + 0.5
+            d.text_embedds_lr = closed_form_tensor((2, 3, H, W), phase=2.1, amp=0.3, freq=0.117) + 0.5
+            x = closed_form_tensor((2, 3, H, W), phase=0.7 + s, amp=1.1)
+            d.img_prev_upsample = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211)
+            out[f"x_s{s}"] = x
+            for t in ts:
+                z = hash_randn((2, 3, H, W), noise_key("step", s, t))
+                rm.noise_like = lambda shape, device, repeat=False, _z=z: _z
+                x = d.p_sample(x, torch.full((2,), t, dtype=torch.long), s).detach()
+                out[f"psample_s{s}_t{t}"] = x
+            out[f"clip_mask_s{s}"] = d.clip_mask
+            out[f"x_recon_prev_s{s}"] = d.x_recon_prev
+            out[f"clip_score_s{s}"] = torch.stack([c.reshape(()) for c in d.clip_score])
+    finally:
+        rm.noise_like = o_noise_like
+        shutil.rmtree(res, ignore_errors=True)
+    save("g15_clip_guided.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g15":
+        workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
+        try:
+            g15(workdir)
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g13":
         workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
         try:
@@ -624,6 +684,7 @@ def main():
         g10(meta, workdir)
         g12(workdir)
         g13(workdir)
+        g15(workdir)
         g14()
     finally:
         shutil.rmtree(workdir, ignore_errors=True)

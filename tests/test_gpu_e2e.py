@@ -361,3 +361,51 @@ def test_integration_option_b_snippet():
     d.noise_fn = lambda kind, shape, s, tt, dev: z.to(dev)
     got = d.p_sample(xs.cuda(), torch.full((2,), 20, device="cuda:0", dtype=torch.long), 1)
     assert rel_l2(got.cpu(), O.p_sample(sched, sd, xs, 20, 1, z, xt)) < 1e-5
+
+
+class _SyntheticScore:
+    """The stand-in for clip.ClipExtractor that fixture G15 was generated with (tests/golden/make_golden.py)."""
+    cfg = {"n_aug": 0}
+
+    def zero_grad(self):
+        pass
+
+    def get_text_embedding(self, text, template=None):
+        return self.emb[template]
+
+    def calculate_clip_loss(self, x, emb):
+        from sinddm_amd.synth import closed_form_tensor
+        w = 0.5 + closed_form_tensor(tuple(x.shape), phase=1.3, amp=0.5, freq=0.173).abs().to(x.device)
+        return (w * (torch.tanh(2.0 * x) - emb) ** 2).mean() * 3.0
+
+
+def test_clip_guided_p_sample_golden(golden):
+    """G15: the guidance branch of p_mean_variance (reference SinDDM/models.py:367-431) run by the REFERENCE with a
+    synthetic differentiable score in place of CLIP: mask creation from the thresholded gradient at the first step,
+    sub-iterations, lambda blending of the previous step's x_recon, the t = 0 step; scale 0 (low-res embedding) and
+    scale 1 (reblurring branch).  Network on the HIP path, guidance on stock PyTorch autograd."""
+    from sinddm_amd.configs import build_diffusion
+    from sinddm_amd.synth import closed_form_tensor, hash_randn, noise_key
+    g = golden("g15_clip_guided.npz")
+    net, d = build_diffusion("C1", dim=32, device=torch.device(DEV))
+    d.clip_guided_sampling = True
+    d.clip_model = _SyntheticScore()
+    d.guidance_sub_iters = [1, 2, 0]
+    d.stop_guidance = 3
+    d.quantile = 0.8
+    d.clip_strength = 0.3
+    d.llambda = 0.2
+    for s, (H, W), ts in ((0, (48, 64), (17, 16)), (1, (67, 90), (17, 16, 0))):
+        d.clip_mask, d.x_recon_prev, d.clip_score = None, None, []
+        d.text_embedds_hr = (closed_form_tensor((2, 3, H, W), phase=0.9, amp=0.4, freq=0.131) + 0.5).to(DEV)
+        d.text_embedds_lr = (closed_form_tensor((2, 3, H, W), phase=2.1, amp=0.3, freq=0.117) + 0.5).to(DEV)
+        x = torch.from_numpy(g[f"x_s{s}"]).to(DEV)
+        d.img_prev_upsample = closed_form_tensor((2, 3, H, W), phase=2.5, amp=0.8, freq=0.211).to(DEV)
+        d.noise_fn = lambda kind, shape, ss, tt, dev: hash_randn(shape, noise_key("step", ss, tt)).to(dev)
+        for t in ts:
+            x = d.p_sample(x, torch.full((2,), t, dtype=torch.long, device=DEV), s)
+            assert rel_l2(x.cpu(), g[f"psample_s{s}_t{t}"]) < 2e-5, (s, t)
+        # the mask is a thresholded comparison: allow a handful of pixels on the threshold to flip
+        assert float((d.clip_mask.cpu() != torch.from_numpy(g[f"clip_mask_s{s}"])).float().mean()) < 1e-3
+        assert rel_l2(d.x_recon_prev.cpu(), g[f"x_recon_prev_s{s}"]) < 2e-5
+        assert rel_l2(torch.stack([c.reshape(()) for c in d.clip_score]), g[f"clip_score_s{s}"]) < 1e-5

@@ -206,3 +206,30 @@ def test_large_batch_index_range():
         y_head = net(x[:2].contiguous(), t[:2].contiguous(), scale=5)
     assert torch.isfinite(y).all()
     assert torch.equal(y[-2:], y_tail) and torch.equal(y[:2], y_head)
+
+
+@pytest.mark.parametrize("dim", [20, 28, 10])
+def test_dims_with_channels_not_multiple_of_4(dim):
+    """dim / 2 or dim not a multiple of 4 (main.py exposes --dim): the 3x3 convs whose C_in % 4 != 0 must take
+    the direct kernel (the packed Winograd image has the second-generation layout, which the first-generation kernel --
+    the only one that accepts such C_in -- cannot read).  Forward and all gradients against the oracle."""
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(dim))
+    net.bind_grads()
+    net.flat_grads.zero_()
+    B, H, W = 2, 21, 38
+    x = hash_randn((B, 3, H, W), 40 + dim)
+    gy = hash_randn((B, 3, H, W), 41 + dim) / (B * 3 * H * W)
+    t = torch.tensor([3, 77])
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd, t.to(DEV), scale=1)
+    y.backward(gy.to(DEV))
+    sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
+    xc = x.clone().requires_grad_(True)
+    yc = O.net_forward(sd, xc, t, 1)
+    yc.backward(gy)
+    assert rel_l2(y.detach().cpu(), yc.detach()) < 1e-5
+    assert rel_l2(xd.grad.cpu(), xc.grad) < 5e-5
+    for name, p in net.named_parameters():
+        assert rel_l2(p.grad.cpu(), sd[name].grad) < 3e-4, name
