@@ -170,7 +170,8 @@ def _traffic(cfg_name):
     profiles/traffic.json -- measured on the box that ran the profile, not on this one -- or (None, None)."""
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-        return t.get(cfg_name, {}).get("conv_bytes_per_launch"), t.get("source")
+        c = t.get(cfg_name, {})
+        return c.get("conv_bytes_per_launch"), c.get("source")
     except Exception:
         return None, None
 

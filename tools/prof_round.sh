@@ -22,9 +22,12 @@ for cfg in c2 c3; do
   run $cfg fetch FETCH_SIZE
   run $cfg write WRITE_SIZE
 done
-run c2 sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVES
+for cfg in c2 c3; do
+  run $cfg sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVES
+  run $cfg l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+done
 cd $ROOT
 for c in c3 c2; do python tools/rocprof_summary.py $(find gpurun_out/prof_${TAG}_$c -name "*results.db" | head -1) > gpurun_out/${TAG}_bench_${c}_kernel_stats.txt 2>&1; grep "^{\"metric\"" gpurun_out/prof_${TAG}_$c.log | tail -1 > gpurun_out/${TAG}_bench_${c}.json; done
 python tools/rocprof_summary.py $(find gpurun_out/prof_${TAG}_train -name "*results.db" | head -1) > gpurun_out/${TAG}_train_kernel_stats.txt 2>&1
-for c in c2 c3; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_${c}_ sq1 grbm fetch write $([ $c = c2 ] && echo sq2) > gpurun_out/${TAG}_pmc_${c}_summary.txt 2>&1; done
+for c in c2 c3; do python tools/pmc_summary.py gpurun_out/pmc_${TAG}_${c}_ sq1 grbm fetch write sq2 l2 > gpurun_out/${TAG}_pmc_${c}_summary.txt 2>&1; done
 head -30 gpurun_out/${TAG}_bench_c3_kernel_stats.txt; head -12 gpurun_out/${TAG}_pmc_c3_summary.txt
