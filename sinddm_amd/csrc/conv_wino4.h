@@ -60,6 +60,17 @@ __device__ unsigned long long g_w4_seg[8 * 256 * 4 * 32];
 #else
 #define W4_SEG(slot) do {} while (0)
 #endif
+#ifdef W4_KSTAMP
+// s_memtime stamps inside the k-steps of chunk 2 of every workgroup's item 3 (debug builds; tools/w4_kstamp.py):
+// [launch % 8][workgroup][wave][k-step 4][stamp 16]
+__device__ unsigned long long g_w4_ks[8 * 256 * 4 * 64];
+#define W4_KS(ks, i) do { if (kst) g_w4_ks[((p.mtp * 256 + blockIdx.x) * 4 + wi) * 64 + (ks) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4_KS(ks, i) do {} while (0)
+#endif
+#ifndef W4_STG_SLOT
+#define W4_STG_SLOT 24         // first of the four slots of k-steps 0 / 1 in which the raw-tile groups of the next chunk are requested
+#endif
 #ifndef W4_PF_BRANCH
 #define W4_PF_BRANCH 1       // 1: the request sits behind a uniform branch on `last chunk`; 0: every chunk issues it, all but
 #endif                       // the last through an empty descriptor (measured: 12 empty loads cost ~600 cycles per chunk)
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     __amdgpu_buffer_rsrc_t rs_st;
     auto stage_load = [&](int n) __attribute__((always_inline)) {                  // n = 2 g + s: group s of channel wi*4 + g
         if (W4_ABL & 1) return;
-        stg[n & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
+        stg[n & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
     };
     // LDS writes of a staged group: four ds_write_b32 at (register + IMMEDIATE) -- left to the compiler they became
     // ds_write2_b32 pairs whose 8-bit offsets need a v_add_u32 per pair, i.e. lone VALU in the MFMA stream.  (The asm
@@ -427,6 +438,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             }
         };
         for (int c = 0; c < nch; ++c) {
+#ifdef W4_KSTAMP
+            const bool kst = l == 4 && c == 2 && blockIdx.x < 256;
+#endif
             const bool last = __builtin_amdgcn_readfirstlane(c + 1 == nch) != 0;
             if (last) make_goff(nx);
             const int dch = last ? 0 : c + 1;
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             const int w_pre[4] = {wcur + 2 * W3_KS_BYTES, wcur + 3 * W3_KS_BYTES, wnext, wnext + W3_KS_BYTES};
             if (last) sstage = base_nx;
             const bool live = dval && dch * 16 + wi * 4 < p.Cin;
-            rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sstage), 0, live ? 4 * (int)HW4 : 0, 0x00020000);
+            rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sstage), 0, live && !(W4_ABL & 32) ? 4 * (int)HW4 : 0, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_pf = last ? rs_op : rs_none, rs_pfb = last ? rs_bias : rs_none;
             w4_static_for<4>([&](auto KS) __attribute__((always_inline)) {
                 constexpr int ks = decltype(KS)::value;
@@ -457,6 +471,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                 // 60 slots: one MFMA + the non-VALU fillers dealt to its gap
                 w4_static_for<2 * MT * W3_NF>([&](auto S) __attribute__((always_inline)) {
                     constexpr int s = decltype(S)::value;
+                    if constexpr (s % 8 == 0) W4_KS(ks, s / 8);                   // stamps 0..7: slots 0, 8, .. 56
+                    if constexpr (s == W4_XF_SLOT + 1) W4_KS(ks, 9);             // behind the transform burst
+                    if constexpr (s == 59) W4_KS(ks, 10);
+                    if constexpr (s >= 42 && s <= 46) W4_KS(ks, 11 + s - 42);       // slots 42..46 one by one
                     constexpr int idx = s >> 1, h = s & 1;
                     constexpr int pos = idx + (idx >= 15 ? 1 : 0);          // slot of the packed order (15 and 31 are padding)
                     constexpr int e = w3_pos_e(pos);
@@ -469,12 +487,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                         raw[wh][cc][hh] = lds_ld(rd[wh][hh], rd_off + cc);
                     }
                     // input transform of the next k-step: one packed burst
+                    if constexpr (s == W4_XF_SLOT) W4_KS(ks, 8);
                     if constexpr (s == W4_XF_SLOT) xf_burst(raw[0], raw[1], v[(ks + 1) & 1], mk);
                     // raw-tile staging of the next chunk, four 16-byte groups per batch: loaded in k-step 0 / 1, written
                     // to LDS a k-step later
-                    if constexpr (ks == 0 && s >= 24 && s < 28) stage_load(s - 24);
+                    if constexpr (ks == 0 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT);
                     if constexpr (ks == 1 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4>{});
-                    if constexpr (ks == 1 && s >= 24 && s < 28) stage_load(s - 24 + 4);
+                    if constexpr (ks == 1 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT + 4);
                     if constexpr (ks == 2 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4 + 16>{});
                     // pass-0 operands of the epilogue, requested late in the item's LAST chunk (W4_PF_KS, W4_PF_SLOT: ahead of
                     // their use).  No branch: every chunk issues the twelve loads, all but the last one through an empty
@@ -602,7 +621,7 @@ inline int conv_wino4_launch(const ConvArgs& a_in, hipStream_t st) {
     a.ntiles = a.B * a.tilesX * a.tilesY;
     a.tiles_per_xcd = (a.ntiles + 7) / 8;
     a.mtp = W3_MT;
-#ifdef W4_TIMING
+#if defined(W4_TIMING) || defined(W4_KSTAMP)
     static int w4_launch_no = 0;
     a.mtp = w4_launch_no++ % 8;                  // (the kernel does not read mtp: stamp row of this launch)
 #endif

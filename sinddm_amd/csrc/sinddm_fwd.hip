@@ -1127,6 +1127,11 @@ int sinddm_debug_w4_seg(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_seg), sizeof(unsigned long long) * n);
 }
 #endif
+#ifdef W4_KSTAMP
+int sinddm_debug_w4_ks(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_ks), sizeof(unsigned long long) * n);
+}
+#endif
 #ifdef W5_TIMING
 int sinddm_debug_w5_seg(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w5_seg), sizeof(unsigned long long) * n);

@@ -6,7 +6,7 @@ CFGS=${3:-"C2 C3"}
 for r in $(seq 1 ${2:-2}); do for v in $1; do for c in $CFGS; do
   cp tools/ab/lib$v.so sinddm_amd/libsinddm_hip.so
   st=20; [ $c = C3 ] && st=4
-  python bench.py --config $c --steps $st --warmup 2 --no-cpu --no-full --no-c2 --no-train 2>&1 | tail -1 | python -c "
+  python bench.py --config $c --steps $st --warmup 2 --no-cpu --no-full --no-c2 --no-train --no-strong 2>&1 | tail -1 | python -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.readline()); r = d['roofline']

@@ -5,14 +5,14 @@
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
-B3="python $ROOT/bench.py --config C3 --steps 5 --warmup 1 --no-full --no-cpu --no-c2 --no-train"
-B2="python $ROOT/bench.py --config C2 --steps 10 --warmup 2 --no-full --no-cpu --no-train"
+B3="python $ROOT/bench.py --config C3 --steps 5 --warmup 1 --no-full --no-cpu --no-c2 --no-train --no-strong"
+B2="python $ROOT/bench.py --config C2 --steps 10 --warmup 2 --no-full --no-cpu --no-train --no-strong"
 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${TAG}_c3 -o bench -- $B3 > $ROOT/gpurun_out/prof_${TAG}_c3.log 2>&1
 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${TAG}_c2 -o bench -- $B2 > $ROOT/gpurun_out/prof_${TAG}_c2.log 2>&1
 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_${TAG}_train -o train -- python $ROOT/tools/train_bench.py 4 3 > $ROOT/gpurun_out/prof_${TAG}_train.log 2>&1
 run() {  # cfg name counters...
   cfg=$1; n=$2; shift; shift
-  cmd="$B2"; [ $cfg = c3 ] && cmd="python $ROOT/bench.py --config C3 --steps 2 --warmup 1 --no-full --no-cpu --no-c2 --no-train"
+  cmd="$B2"; [ $cfg = c3 ] && cmd="python $ROOT/bench.py --config C3 --steps 2 --warmup 1 --no-full --no-cpu --no-c2 --no-train --no-strong"
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $ROOT/gpurun_out/pmc_${TAG}_${cfg}_$n -o pmc --output-format csv -- $cmd > $ROOT/gpurun_out/pmc_${TAG}_${cfg}_$n.log 2>&1
   echo "pass $cfg $n rc=$?"
 }
