@@ -203,13 +203,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         // (a 16-byte group that starts inside the image may run past its right edge into the next row when W % 4 != 0)
         nvn = W - (it.x0 + 4 * tc_ - 1);
     };
-    f32x4 stg[4];                                   // two batches of four 16-byte groups per chunk
+#ifndef W4_STG_SPREAD
+#define W4_STG_SPREAD 1       // 1: the eight raw-tile requests of a chunk W4_STG_GAP slots apart, each written to LDS W4_STG_DIST slots
+#define W4_STG_GAP 15          //    later (0: two batches of four back to back: +2-3 % per launch at C3 -- the bursts of
+#define W4_STG_DIST 60         //    HBM-latency loads hold up the weight refills queued behind them, vector memory returns in order)
+#endif
+    f32x4 stg[W4_STG_SPREAD ? 8 : 4];               // two batches of four 16-byte groups per chunk (spread: a ring)
     const unsigned HW4 = (unsigned)HW * 4u;
     auto plane_ptr = [&](int ib) { return p.in + ((size_t)ib * p.Cin + wi * 4) * HW; };
     __amdgpu_buffer_rsrc_t rs_st;
     auto stage_load = [&](int n) __attribute__((always_inline)) {                  // n = 2 g + s: group s of channel wi*4 + g
         if (W4_ABL & 1) return;
-        stg[n & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
+        stg[W4_STG_SPREAD ? n : n & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
     };
     // LDS writes of a staged group: four ds_write_b32 at (register + IMMEDIATE) -- left to the compiler they became
     // ds_write2_b32 pairs whose 8-bit offsets need a v_add_u32 per pair, i.e. lone VALU in the MFMA stream.  (The asm
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         constexpr int off = (n >> 1) * W4_PS * 4;
         static_assert(off + 12 < 65536, "ds_write_b32 immediate offset");
         const unsigned addr = swb[n & 1];                   // (locals: asm operands do not capture in a generic lambda)
-        const float val = stg[n & 3][e];
+        const float val = stg[W4_STG_SPREAD ? n : n & 3][e];
         asm volatile("ds_write_b32 %0, %1 offset:%c2" ::"v"(addr), "v"(val), "n"(off + 4 * e) : "memory");
     };
 
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     auto stage_store0 = [&](int n) {
         float* d = smem + (wi * 4 + (n >> 1)) * W4_PS + swo[n & 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = stg[n & 3][e];
+        for (int e = 0; e < 4; ++e) d[e] = stg[W4_STG_SPREAD ? n : n & 3][e];
     };
     rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane_ptr(it.b)), 0, 4 * (int)HW4, 0x00020000);
 #pragma unroll
@@ -491,10 +496,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     if constexpr (s == W4_XF_SLOT) xf_burst(raw[0], raw[1], v[(ks + 1) & 1], mk);
                     // raw-tile staging of the next chunk, four 16-byte groups per batch: loaded in k-step 0 / 1, written
                     // to LDS a k-step later
+#if W4_STG_SPREAD
+                    {   // request n at chunk slot 2 + GAP n, its four LDS writes from chunk slot 2 + DIST + GAP n on
+                        constexpr int G = ks * 60 + s;
+                        constexpr int G0 = 2, G1 = 2 + W4_STG_DIST;
+                        static_assert(G1 + 7 * W4_STG_GAP + 3 < 180, "the last LDS write must precede the chunk barrier");
+                        if constexpr (G >= G0 && G < G0 + W4_STG_GAP * 8 && (G - G0) % W4_STG_GAP == 0) stage_load((G - G0) / W4_STG_GAP);
+                        if constexpr (G >= G1 && G < G1 + W4_STG_GAP * 8 && (G - G1) % W4_STG_GAP < 4)
+                            stage_store(std::integral_constant<int, (G - G1) / W4_STG_GAP * 4 + (G - G1) % W4_STG_GAP>{});
+                    }
+#else
                     if constexpr (ks == 0 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT);
                     if constexpr (ks == 1 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4>{});
                     if constexpr (ks == 1 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT + 4);
                     if constexpr (ks == 2 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4 + 16>{});
+#endif
                     // pass-0 operands of the epilogue, requested late in the item's LAST chunk (W4_PF_KS, W4_PF_SLOT: ahead of
                     // their use).  No branch: every chunk issues the twelve loads, all but the last one through an empty
                     // descriptor (no memory traffic; the registers are dead until the epilogue)
