@@ -177,9 +177,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
 
     // ---- raw tile staging: 100 sixteen-byte groups per channel plane = two loads per channel ----
     constexpr unsigned OOB = 0x40000000u;
-    // (the second load has 36 live lanes; lanes 36..63 repeat groups 64..91 -- same data to the same address -- so
-    // that neither the load nor the LDS write needs an exec mask)
-    auto stage_li = [&](int s) { return s == 0 ? lane : 64 + (lane < 36 ? lane : lane - 36); };
+    // lane -> (halo row, 16-byte group) of its two requests per plane.  First request: rows 0..7 x groups 0..7 -- with the
+    // odd row stride a half wave's four ds_write_b32 (rows r..r+3 x 8 groups) hit 32 distinct banks; second request: groups
+    // 8, 9 of all ten rows (lanes 0..19) and groups 0..7 of rows 8, 9 (lanes 20..35); lanes 36..63 repeat lanes 0..27 --
+    // same data to the same address -- so that neither the load nor the LDS write needs an exec mask.  (Row-major over
+    // all ten groups, the first form, was 2- to 3-way conflicted: 0.17 of the kernel's LDS cycles.)
+    auto stage_li = [&](int s) {
+        if (s == 0) return (lane >> 3) * 10 + (lane & 7);
+        const int m = lane < 36 ? lane : lane - 36;
+        return m < 20 ? (m >> 1) * 10 + 8 + (m & 1) : (8 + ((m - 20) >> 3)) * 10 + ((m - 20) & 7);
+    };
     unsigned goff[2];
     int swo[2];                                     // LDS float offset of this lane's group inside a plane
     // EDGE builds: patch column c of this lane's tiles lies inside the image iff c < nv (item) / nvn (next item).  (A count
