@@ -340,10 +340,34 @@ def train_leg(ctx, steps=5, warmup=2):
         loss = one()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"workload": f"C2 finest scale {H}x{W}, batch 32, dim=160: p_losses forward + backward + fused Adam",
-            "ms_per_step": round(dt * 1e3, 2), "steps_per_sec": round(1 / dt, 3),
-            "net_tflops_3x_forward": round(3 * NET_FLOP_PER_PIXEL * 32 * H * W / dt / 1e12, 1),
-            "loss_finite": bool(torch.isfinite(loss))}
+    # roofline of the step's biggest kernel: the Winograd-domain 3x3 weight gradient (HIP events around each of its
+    # launches, one extra untimed step; F(2x2,3x3): 16/36 of 2*B*H*W*Cout*Cin*9 executed)
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    lib.sinddm_prof_begin()
+    one()
+    torch.cuda.synchronize()
+    wg_ms, wg_n, wg_fl, wg_ex = _prof(lib, 4, 0)
+    cv_ms, cv_n, cv_fl, cv_ex = _prof(lib, 1, 1)
+    rec = {"workload": f"C2 finest scale {H}x{W}, batch 32, dim=160: p_losses forward + backward + fused Adam",
+           "ms_per_step": round(dt * 1e3, 2), "steps_per_sec": round(1 / dt, 3),
+           "net_tflops_3x_forward": round(3 * NET_FLOP_PER_PIXEL * 32 * H * W / dt / 1e12, 1),
+           "loss_finite": bool(torch.isfinite(loss))}
+    if wg_n:
+        ex = wg_ex / (wg_ms * 1e-3) / 1e12
+        rec["wgrad_roofline"] = {
+            "kernel": "wgrad_wino_kernel", "bound": "mfma", "launches_per_step": wg_n,
+            "ms_per_step": round(wg_ms, 3), "share_of_step": round(wg_ms / (dt * 1e3), 4),
+            "achieved": round(ex, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4),
+            "algorithmic_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1)}
+    if cv_n:
+        ex = cv_ex / (cv_ms * 1e-3) / 1e12
+        rec["conv_roofline"] = {
+            "kernel": "conv_wino4_kernel (forward + both data gradients)", "launches_per_step": cv_n,
+            "ms_per_step": round(cv_ms, 3), "share_of_step": round(cv_ms / (dt * 1e3), 4),
+            "achieved": round(ex, 2), "frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4)}
+    return rec
 
 
 def cpu_leg(cfg, n_scales, B, H, W, s, total_t):

@@ -25,9 +25,16 @@ int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_
 int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
                      double* conv_exec_flops_total);
 /* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino2/3/4/5_kernel), 2 = 1x1 convs,
- * 3 = direct 3x3 (conv_mfma_dma_kernel).  reset = 0 keeps the records so that several kinds can be queried. */
+ * 3 = direct 3x3 (conv_mfma_dma_kernel), 4 = Winograd-domain 3x3 weight gradient (wgrad_wino_kernel, F(2x2): 16/36 of
+ * 2*B*H*W*Cout*Cin*9 executed).  reset = 0 keeps the records so that several kinds can be queried. */
 int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total,
                      double* exec_flops_total, int reset);
+
+/* Host-only (no device call): the workgroup -> (slab, pixel split) table wgrad_wino_kernel would be launched with for a
+ * Cin -> Cout 3x3 weight gradient over `ntiles` 4x16-pixel tiles on `ncu` compute units.  wg_out (>= 512 entries) receives
+ * slab << 16 | split per workgroup id, splits_out (>= 64) the number of pixel splits of each (co block, ci block) slab.
+ * Returns the number of workgroups (> 0) or a negative SINDDM_E_* code.  For tests of the load balance. */
+int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int32_t* splits_out);
 
 #ifdef __cplusplus
 }

@@ -525,18 +525,31 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         w.tilesX = (W + WW_TW - 1) / WW_TW;
         w.tilesY = (H + WW_TH - 1) / WW_TH;
         w.ntiles = B * w.tilesX * w.tilesY;
-        const int pairs = w.coblks * w.ciblks;
-        int S = (device_cu_count() / pairs) / 8 * 8;
-        if (S < 8) S = 8;
-        const int cap = (w.ntiles + 7) / 8 * 8;
-        if (S > cap) S = cap;
-        w.S = S;
+        const int nwg = ww_build_map(w, device_cu_count());
+        if (nwg <= 0) return SINDDM_E_BADSHAPE;
         const int n = Cout * Cin * 9;
         hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
-        constexpr size_t lds = (size_t)2 * WW_BUF * sizeof(float);
-        hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)(pairs * S)), dim3(WW_THREADS), lds, st, w);
+        constexpr size_t lds = (size_t)WW_STAGES * WW_BUF * sizeof(float);
+        // (more than 64 KB of dynamic LDS needs the per-function opt-in; idempotent)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ConvProfiler& prof = conv_profiler();
+        const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
+        if (rec) {
+            while (prof.created <= prof.used) {
+                (void)hipEventCreate(&prof.ev[2 * prof.created]);
+                (void)hipEventCreate(&prof.ev[2 * prof.created + 1]);
+                ++prof.created;
+            }
+            (void)hipEventRecord(prof.ev[2 * prof.used], st);
+        }
+        hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
         SINDDM_LAUNCH_CHECK();
+        if (rec) {
+            (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
+            const double fl = 2.0 * B * H * W * (double)Cout * Cin * 9.0;
+            prof.note(4, fl, fl * 16.0 / 36.0);      // kind 4 = Winograd-domain weight gradient, F(2x2): 16/36 executed
+        }
         hipLaunchKernelGGL(wgrad_unstage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scr, gw, Cin, n);
         SINDDM_LAUNCH_CHECK();
         return 0;
@@ -1194,6 +1207,20 @@ int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* em
                        ema, step_size, beta1, beta2, eps, bc2_sqrt, ema_decay, mode, (long long)n);
     SINDDM_LAUNCH_CHECK();
     return 0;
+}
+
+int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int32_t* splits_out) {
+    if (Cin < 1 || Cout < WW_CO || Cout % WW_CO || ntiles < 1 || !wg_out || !splits_out) return SINDDM_E_BADARG;
+    WwArgs w{};
+    w.Cin = Cin; w.Cout = Cout;
+    w.coblks = Cout / WW_CO;
+    w.ciblks = (Cin + WW_CI - 1) / WW_CI;
+    w.ntiles = (int)(ntiles > 0x7fffffff ? 0x7fffffff : ntiles);
+    const int n = ww_build_map(w, ncu);
+    if (n <= 0) return SINDDM_E_BADSHAPE;
+    for (int i = 0; i < n; ++i) wg_out[i] = w.map.wg[i];
+    for (int q = 0; q < w.coblks * w.ciblks; ++q) splits_out[q] = w.map.S[q];
+    return n;
 }
 
 }  // extern "C"

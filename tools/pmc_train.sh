@@ -12,4 +12,5 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 run sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVES
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-cd $ROOT; python tools/pmc_summary.py gpurun_out/pmct_${TAG}_ sq1 sq2 fetch write > gpurun_out/pmct_${TAG}_summary.txt; cat gpurun_out/pmct_${TAG}_summary.txt | cut -c1-400
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+cd $ROOT; python tools/pmc_summary.py gpurun_out/pmct_${TAG}_ sq1 sq2 fetch write grbm > gpurun_out/pmct_${TAG}_summary.txt; cat gpurun_out/pmct_${TAG}_summary.txt | cut -c1-400
