@@ -200,8 +200,15 @@ def test_second_forward_before_backward_raises():
 
 
 def test_net_backward_full_size_vs_oracle_autograd():
-    """The training shape of config C2: finest scale 186x248, dim = 160 (batch 2 bounds the oracle's CPU autograd to
-    ~20 s; samples are independent in every kernel).  All 52 parameter gradients + the input gradient."""
+    """The training shape of config C2: finest scale 186x248, dim = 160 (batch 2 bounds the oracle's CPU autograd;
+    samples are independent in every kernel).  All 52 parameter gradients + the input gradient.
+
+    The reference value is the oracle's autograd in FLOAT64; the tolerance of every tensor is calibrated by the error the
+    oracle's own float32 autograd makes against it (3x that, floor 5e-5): the sums over 46 128 pixels of white-noise
+    gradients (condition path, depthwise bias) carry 3e-4..5e-4 of rounding noise in ANY fp32 evaluation, the CPU's
+    included.  tools/bwd_bisect.py / profiles/r03_bwd_tolerance_bisect.txt: F(2x4), F(2x2) and direct-convolution data
+    gradients sit at 5.7e-6 / 4.1e-6 / 4.0e-6 on the input gradient (CPU fp32: 3.8e-6) and 3.6e-4 / 3.1e-4 / 5.4e-4 on
+    the condition path (CPU fp32: 4.3e-4) -- the widths are summation noise, not Winograd."""
     from sinddm_amd.models import SinDDMNet
     dim, B, H, W = 160, 2, 186, 248
     net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
@@ -214,21 +221,27 @@ def test_net_backward_full_size_vs_oracle_autograd():
     xd = x.to(DEV).requires_grad_(True)
     y = net(xd, t.to(DEV), scale=4)
     y.backward(gy.to(DEV))
-    sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
-    xc = x.clone().requires_grad_(True)
-    yc = O.net_forward(sd, xc, t, 4)
-    yc.backward(gy)
-    assert rel_l2(y.detach().cpu(), yc.detach()) < 1e-5
-    assert rel_l2(xd.grad.cpu(), xc.grad) < 5e-5
-    worst = ("", 0.0)
+
+    def oracle(dtype):
+        torch.set_default_dtype(dtype)
+        try:
+            sd = {k: v.to(dtype).clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
+            xc = x.to(dtype).clone().requires_grad_(True)
+            yc = O.net_forward(sd, xc, t, 4)
+            yc.backward(gy.to(dtype))
+        finally:
+            torch.set_default_dtype(torch.float32)
+        return yc.detach(), xc.grad, {k: v.grad for k, v in sd.items()}
+
+    y64, gx64, g64 = oracle(torch.float64)
+    y32, gx32, g32 = oracle(torch.float32)
+    assert rel_l2(y.detach().cpu().double(), y64) < 2e-6
+    assert rel_l2(xd.grad.cpu().double(), gx64) < max(2e-5, 3 * rel_l2(gx32.double(), gx64))
+    worst = ("", 0.0, 0.0)
     for name, p in net.named_parameters():
-        err = rel_l2(p.grad.cpu(), sd[name].grad)
-        worst = max(worst, (name, err), key=lambda v: v[1])
-        # (the per-sample condition gradients and the depthwise bias gradient are plain sums of dH over all 46 128 pixels with
-        # heavy cancellation -- gy is white noise: the rounding noise of the data-gradient convs (atomics order, and since
-        # round 2 the F(2x4) Winograd transforms) shows up relatively largest there: up to 5e-4, against < 1.2e-4 for every
-        # conv weight, 5e-6 for the input gradient and 5e-7 for the forward output; the fp32 CPU autograd it is compared
-        # with carries noise of the same order in exactly these sums)
-        cond_path = ".mlp." in name or "time_mlp" in name or "time_reshape" in name or name.endswith("ds_conv.bias")
-        assert err < (8e-4 if cond_path else 3e-4), (name, err)
-    print("full-size backward: worst rel-L2 gradient error", worst)
+        err = rel_l2(p.grad.cpu().double(), g64[name])
+        cpu = rel_l2(g32[name].double(), g64[name])
+        worst = max(worst, (name, err, cpu), key=lambda v: v[1])
+        assert err < max(5e-5, 3 * cpu), (name, err, cpu)
+        assert err < 1.5e-3, (name, err)
+    print("full-size backward: worst rel-L2 gradient error vs float64 (HIP, CPU fp32)", worst)
