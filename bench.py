@@ -291,11 +291,15 @@ def full_sample_leg(ctx, d, cfg, B, sizes=None):
     mul = cfg.get("scale_mul", (1, 1))
     ctx.barrier()
     t0 = time.perf_counter()
+    marks = [t0]
     cur = d.sample(batch_size=B, scale_0_size=d.target_size(0, mul, True, 0), s=0)
+    torch.cuda.synchronize()
+    marks.append(time.perf_counter())
     for si in range(1, n_scales):
         cur = d.sample_via_scale(B, cur, s=si, scale_mul=mul, custom_sample=True, custom_img_size_idx=si,
                                  custom_t=d.num_timesteps_ideal[si])
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()          # (one sync per pyramid scale: this rank's per-scale wall clock)
+        marks.append(time.perf_counter())
     tg = time.perf_counter()
     cur = ctx.gather_shards(cur, sizes) if sizes else ctx.gather(cur, B)
     torch.cuda.synchronize()
@@ -303,10 +307,15 @@ def full_sample_leg(ctx, d, cfg, B, sizes=None):
     ctx.barrier()
     ft = ctx.max_over_ranks(time.perf_counter() - t0)
     pix_steps = 0
+    per_scale = []
     for si in range(n_scales):
         h, w = d.target_size(si, mul, True, si)
         pix_steps += h * w * d.num_timesteps_ideal[si]
+        dts = marks[si + 1] - marks[si]
+        per_scale.append({"size": [h, w], "steps": int(d.num_timesteps_ideal[si]), "seconds": round(dts, 4),
+                          "mpx_steps_per_sec": round(B * h * w * d.num_timesteps_ideal[si] / dts / 1e6, 1)})
     return {"imgs_per_sec": round(total / ft, 4), "seconds": round(ft, 3), "images": total,
+            "per_scale_this_rank": per_scale,
             "all_gather_seconds": round(tg, 6) if ctx.world > 1 else 0.0,
             "net_evals_per_image": sum(d.num_timesteps_ideal),
             "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * total / ft / 1e12, 2),

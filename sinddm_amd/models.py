@@ -643,6 +643,10 @@ class MultiScaleGaussianDiffusion(nn.Module):
                          repeat_noise: bool = False) -> torch.Tensor:
         """One reverse step with the timestep known on the host: net forward + ONE fused kernel."""
         if self.clip_guided_sampling:
+            if self.clip_model is None or self.guidance_sub_iters is None or self.stop_guidance is None:
+                raise RuntimeError("clip_guided_sampling is set but clip_model / guidance_sub_iters / stop_guidance are not: "
+                                   "CLIP is outside this build -- assign any object with zero_grad() and a differentiable "
+                                   "calculate_clip_loss(image, text_embedds) (reference models.py:193-220, 367-421)")
             return self._p_sample_guided(x.contiguous(), int(t), int(s), clip_denoised, repeat_noise)
         lib = _lib.load()
         x = x.contiguous()
