@@ -10,7 +10,7 @@ python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -15 > gpurun_ou
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 python bench.py > gpurun_out/bench_$TAG.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-full --no-cpu > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-full --no-cpu --no-strong > $ROOT/gpurun_out/prof_$TAG.log 2>&1
 cd $ROOT
 tail -4 gpurun_out/tests_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log; tail -1 gpurun_out/bench_$TAG.log; tail -2 gpurun_out/prof_$TAG.log
 find gpurun_out/prof_$TAG -type f | head
