@@ -34,6 +34,9 @@ namespace sinddm {
 #ifndef SINDDM_WGRAD_WINO     // 1: Winograd-domain 3x3 weight gradient
 #define SINDDM_WGRAD_WINO 1
 #endif
+#ifndef SINDDM_WGRAD_WIDE     // 1: W % 4 == 0 launches of the Winograd weight gradient on wgrad_wino_wide_kernel (16-byte DMA)
+#define SINDDM_WGRAD_WIDE 1
+#endif
 #ifndef SINDDM_WGRAD_W3       // 1: 80x80-slab direct 3x3 weight gradient where the Winograd one does not apply
 #define SINDDM_WGRAD_W3 1
 #endif

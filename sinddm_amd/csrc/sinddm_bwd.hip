@@ -530,9 +530,13 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         const int n = Cout * Cin * 9;
         hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
-        constexpr size_t lds = (size_t)WW_STAGES * WW_BUF * sizeof(float);
+        // rows of 16-byte groups (W % 4 == 0): the variant with 16-byte DMA and ds_read_b64 operands
+        const bool wide = SINDDM_WGRAD_WIDE && W % 4 == 0;
+        const size_t lds = (size_t)WW_STAGES * (wide ? WX_BUF : WW_BUF) * sizeof(float);
         // (more than 64 KB of dynamic LDS needs the per-function opt-in; idempotent)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(wide ? reinterpret_cast<const void*>(&wgrad_wino_wide_kernel)
+                                       : reinterpret_cast<const void*>(&wgrad_wino_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         ConvProfiler& prof = conv_profiler();
         const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
         if (rec) {
@@ -543,7 +547,8 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
             }
             (void)hipEventRecord(prof.ev[2 * prof.used], st);
         }
-        hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
+        if (wide) hipLaunchKernelGGL(wgrad_wino_wide_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
+        else hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
         SINDDM_LAUNCH_CHECK();
         if (rec) {
             (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
