@@ -83,3 +83,60 @@ def test_conv_wino4_owns_the_agprs():
         meta = s[end:end + 8000]
         assert re.search(r"NumAgprs:\s+128\b", meta) and re.search(r"ScratchSize:\s+0\b", meta), m.group(1)
         assert re.search(r"Occupancy:\s+2\b", meta), m.group(1)
+
+
+WGRAD_TU = """
+#include "conv_mfma.h"
+#include "wgrad_wino.h"
+namespace sinddm {
+ConvProfiler& conv_profiler() { static ConvProfiler p; return p; }
+void touch(const WwArgs& w, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_wino_wide_kernel, dim3(1), dim3(WW_THREADS), 0, st, w);
+}
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_wgrad_wide_kernel_reads_lds_with_plain_b64_and_dmas_16_bytes():
+    """wgrad_wino.h's wide kernel relies on two things the compiler could silently undo: its operand reads must stay
+    single ds_read_b64 (fused into ds_read2_b64 / ds_read2st64_b64 the 16-byte-slot LDS image is 2-way bank-conflicted),
+    and the tile loop body of every (frequency, n-tile count) copy must be ONE basic block (60 / 40 / 20 MFMAs), i.e. free
+    of branches -- the reads are scheduled a k-step ahead inside it."""
+    from sinddm_amd import build
+    tmp = tempfile.mkdtemp(prefix="wwisa")
+    try:
+        src = os.path.join(tmp, "t.hip")
+        with open(src, "w") as f:
+            f.write(WGRAD_TU)
+        flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+        subprocess.check_call([HIPCC, *flags, "-I", os.path.join(ROOT, "include"), "-I", build.CSRC,
+                               "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "t.s")],
+                              stderr=subprocess.DEVNULL)
+        s = open(os.path.join(tmp, "t.s")).read()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    m = re.search(r"^(_ZN6sinddm22wgrad_wino_wide_kernel\w+):", s, re.M)
+    assert m
+    end = s.index(".Lfunc_end", m.start())
+    body = [l.strip() for l in s[m.start():end].split("\n") if l.strip() and not l.strip().startswith(";")]
+    assert not [l for l in body if l.startswith("ds_read2")], "fused LDS reads"
+    assert sum(l.startswith("ds_read_b64") for l in body) > 2000
+    assert any(l.startswith("buffer_load_dwordx4") and " lds" in l for l in body)
+    assert not [l for l in body if l.startswith("buffer_load_dword ") and " lds" in l]
+    assert sum(l.startswith("v_mfma_f32_16x16x4_f32") for l in body) == 16 * (60 + 40 + 20)
+    # basic blocks by label: the 48 loop bodies hold 60, 40 or 20 MFMAs each, nothing else holds any
+    counts, cur = [], 0
+    for l in body:
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            counts.append(cur)
+            cur = 0
+        elif l.startswith("v_mfma"):
+            cur += 1
+    counts.append(cur)
+    held = sorted(c for c in counts if c)
+    assert held == sorted([60] * 16 + [40] * 16 + [20] * 16), held
+    meta = s[end:end + 8000]
+    assert re.search(r"Occupancy:\s+4\b", meta)
+    scratch = int(re.search(r"ScratchSize:\s+(\d+)", meta).group(1))
+    assert scratch <= 64, scratch                  # (a few spilled address registers in the 4-term copies; none holds data)
