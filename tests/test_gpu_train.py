@@ -204,7 +204,7 @@ def test_net_backward_full_size_vs_oracle_autograd():
     samples are independent in every kernel).  All 52 parameter gradients + the input gradient.
 
     The reference value is the oracle's autograd in FLOAT64; the tolerance of every tensor is calibrated by the error the
-    oracle's own float32 autograd makes against it (3x that, floor 5e-5): the sums over 46 128 pixels of white-noise
+    oracle's own float32 autograd makes against it (3x the worst of the tensor's class, floor 5e-5): the sums over 46 128 pixels of white-noise
     gradients (condition path, depthwise bias) carry 3e-4..5e-4 of rounding noise in ANY fp32 evaluation, the CPU's
     included.  tools/bwd_bisect.py / profiles/r03_bwd_tolerance_bisect.txt: F(2x4), F(2x2) and direct-convolution data
     gradients sit at 5.7e-6 / 4.1e-6 / 4.0e-6 on the input gradient (CPU fp32: 3.8e-6) and 3.6e-4 / 3.1e-4 / 5.4e-4 on
@@ -237,11 +237,21 @@ def test_net_backward_full_size_vs_oracle_autograd():
     y32, gx32, g32 = oracle(torch.float32)
     assert rel_l2(y.detach().cpu().double(), y64) < 2e-6
     assert rel_l2(xd.grad.cpu().double(), gx64) < max(2e-5, 3 * rel_l2(gx32.double(), gx64))
-    worst = ("", 0.0, 0.0)
+    # per class of tensors (the condition path's and the biases' gradients are plain sums over all pixels, accumulated
+    # with atomics on the GPU: their rounding noise varies from run to run): HIP error of every tensor < 3x the WORST
+    # float32-CPU error in its class
+    def klass(name):
+        if ".mlp." in name or "time_mlp" in name or "time_reshape" in name or name.endswith("ds_conv.bias"):
+            return "cond_path"
+        return "weight" if name.endswith("weight") else "bias"
+    errs = {}
     for name, p in net.named_parameters():
-        err = rel_l2(p.grad.cpu().double(), g64[name])
-        cpu = rel_l2(g32[name].double(), g64[name])
-        worst = max(worst, (name, err, cpu), key=lambda v: v[1])
-        assert err < max(5e-5, 3 * cpu), (name, err, cpu)
-        assert err < 1.5e-3, (name, err)
-    print("full-size backward: worst rel-L2 gradient error vs float64 (HIP, CPU fp32)", worst)
+        errs[name] = (rel_l2(p.grad.cpu().double(), g64[name]), rel_l2(g32[name].double(), g64[name]))
+    cpu_worst = {}
+    for name, (e, c) in errs.items():
+        cpu_worst[klass(name)] = max(cpu_worst.get(klass(name), 0.0), c)
+    for name, (e, c) in errs.items():
+        assert e < max(5e-5, 3 * cpu_worst[klass(name)]), (name, e, c, cpu_worst)
+        assert e < 1.5e-3, (name, e)
+    worst = max(errs.items(), key=lambda kv: kv[1][0])
+    print("full-size backward: worst rel-L2 gradient error vs float64 (HIP, CPU fp32)", worst, cpu_worst)
