@@ -75,13 +75,28 @@ def verify() -> None:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    cmd = [_hipcc(), *FLAGS, "-I", INCLUDE, *srcs, "-o", LIB]
-    if verbose:
-        print("[sinddm_amd.build]", " ".join(cmd), flush=True)
     if os.path.exists(STAMP):
         os.remove(STAMP)
-    subprocess.check_call(cmd)
+    # the two translation units compile side by side (the backward one carries 96 specialised copies of the
+    # weight-gradient loop: ~100 s on its own), then one link
+    import tempfile
+    cflags = [f for f in FLAGS if f != "-shared"]
+    with tempfile.TemporaryDirectory(prefix="sinddm_build") as tmp:
+        procs, objs = [], []
+        for src in SOURCES:
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            cmd = [_hipcc(), *cflags, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print("[sinddm_amd.build]", " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
+            objs.append(obj)
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB]
+        if verbose:
+            print("[sinddm_amd.build]", " ".join(link), flush=True)
+        subprocess.check_call(link)
     with open(STAMP, "w") as f:
         f.write(source_hash() + "\n")
     return LIB

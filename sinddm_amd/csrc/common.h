@@ -50,6 +50,16 @@ namespace sinddm {
 #define SINDDM_WGRAD_ABL 0
 #endif
 
+// Barrier that also publishes this wave's LDS-DMA (buffer_load ... lds).  __syncthreads() is a WORKGROUP-scope fence, for
+// which the gfx950 memory model waits on lgkmcnt only: an LDS-DMA counts on vmcnt and may still be in flight when the
+// other waves pass the barrier and read its destination.  (The compiler does wait before the issuing wave's OWN ds_reads
+// of the destination, which hid the hole wherever a DMA had a whole tile of slack; wgrad_wino_wide_kernel's 16-channel
+// slabs, whose tiles are shorter than an HBM round trip, showed it as run-to-run differences of 1e-3.)
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 

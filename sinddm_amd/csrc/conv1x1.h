@@ -72,7 +72,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
     const int aBase = kq * CO_LDS + l16;
     const int bBase = W_FLOATS + kq * C1_PS + wave * 64 + l16 * 4;
     issue(0, smem);
-    __syncthreads();
+    dma_barrier();
     for (int c = 0; c < nch; ++c) {
         const float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv1x1_mfma_kernel(ConvArgs p, in
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         }
-        __syncthreads();
+        dma_barrier();
     }
 
     const int px0 = p0 + wave * 64 + l16 * 4;          // this lane's 4 consecutive pixels

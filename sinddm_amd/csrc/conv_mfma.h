@@ -236,19 +236,19 @@ __global__ __launch_bounds__(WV * 64, (WV == 16 ? 4 : (WV == 8 ? 4 : 1))) void c
     const int bBase = 9 * KC * CO_LDS + kq * G::PS + (wave * G::RPW) * G::RS + l16;
 
     issue(0, smem);
-    __syncthreads();                       // (carries the vmcnt(0) of the pending DMA)
+    dma_barrier();                       // (vmcnt(0) + barrier: the pending DMA is published)
     int c = 0;
     for (; c < p.nch3; ++c) {              // 3x3 chunks
         float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
         conv_compute_chunk<MT, NT, 9, PIN, WV>(acc, cur, cur, aBase, bBase);
-        __syncthreads();                   // everyone done with `cur`; DMA of chunk c+1 has landed
+        dma_barrier();                   // everyone done with `cur`; DMA of chunk c+1 has landed
     }
     for (; c < nch; ++c) {                 // fused 1x1 (residual projection) chunks
         float* cur = smem + (c & 1) * BUF;
         if (c + 1 < nch) issue(c + 1, smem + ((c + 1) & 1) * BUF);
         conv_compute_chunk<MT, NT, 1, PIN, WV>(acc, cur, cur, aBase, bBase);
-        __syncthreads();
+        dma_barrier();
     }
 
 #pragma unroll

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
     load_w(0, it.cb, 0, 0);
     load_w(1, it.cb, 0, 1);
     issue(it, 0, smem);
-    __syncthreads();
+    dma_barrier();
 
     const int tr = lane >> 4, tc = lane & 15;   // epilogue role of a lane: 2x2 tile (tile-row, tile-col)
     const int lt = lane < WG::NTILES ? lane : 0;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WN_THREADS) void conv_wino_kernel(ConvArgs p, int i
 #ifdef SINDDM_WINO_TIMING
             if (dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 1] = __builtin_amdgcn_s_memtime();
 #endif
-            if (!(SINDDM_WINO_ABL & 8)) __syncthreads();
+            if (!(SINDDM_WINO_ABL & 8)) dma_barrier();
 #ifdef SINDDM_WINO_TIMING
             if (dbg) g_wino_dbg[((dbg_item * 16 + c) * 16 + xi) * 4 + 2] = __builtin_amdgcn_s_memtime();
 #endif

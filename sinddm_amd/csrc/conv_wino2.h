@@ -285,7 +285,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
     int wb_it = wbase(it.cb);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) load_w(mt, wb_it, wb_it, 0);
-    __syncthreads();
+    dma_barrier();
     int wcur = wb_it;                              // weights of (item, chunk, this wave's frequency row, k-step 0, m-tile 0)
     const float* sstage = plane_ptr(it.b) + (size_t)16 * HW;   // planes of the chunk to stage next (chunk 1 of the item)
     int nb = 0;                                    // raw buffer holding the current chunk (runs across items)

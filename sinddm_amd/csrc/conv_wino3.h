@@ -183,7 +183,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
 #pragma unroll
     for (int q = 0; q < W3_Q; ++q)
         aq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane + q * 1024, wb_it, 0));
-    __syncthreads();
+    dma_barrier();
     int wcur = wb_it;
     const float* sstage = plane_ptr(it.b) + (size_t)16 * HW;
     int nb = 0;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_mfma_kernel(WgradArgs p) 
     int it = 0;
     if (s < p.ntiles) issue(s, smem);
     for (int tile = s; tile < p.ntiles; tile += p.S, ++it) {
-        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+        dma_barrier();          // DMA of `tile` landed (dma_barrier: vmcnt(0) + barrier); previous tile consumed
         float* cur = smem + (it & 1) * BUF;
         if (tile + p.S < p.ntiles) issue(tile + p.S, smem + ((it + 1) & 1) * BUF);
 #pragma unroll 1
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(WgradArgs p) {
         for (int g = 0; g < NG; ++g) issue_group(ta, smem, g);
     }
     for (int tile = s; tile < p.ntiles; tile += p.S, ++it) {
-        __syncthreads();          // DMA of `tile` landed (vmcnt(0) is part of the barrier); previous tile consumed
+        dma_barrier();          // DMA of `tile` landed (dma_barrier: vmcnt(0) + barrier); previous tile consumed
         const float* cur = smem + (it & 1) * W3_BUF;
         float* nxt = smem + ((it + 1) & 1) * W3_BUF;
         const bool pf = tile + p.S < p.ntiles && !(p.abl & 1);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(1024) void wgrad1x1_kernel(WgradArgs p) {
     int it = 0;
     if (t_begin < t_end) issue(smem);
     for (int tile = t_begin; tile < t_end; ++tile, ++it) {
-        __syncthreads();
+        dma_barrier();
         const float* cur = smem + (it & 1) * W1_BUF;
         if (tile + 1 < t_end) issue(smem + ((it + 1) & 1) * W1_BUF);
         if (active) {

@@ -124,6 +124,7 @@ inline int ww_build_map(WwArgs& w, int ncu) {
 __device__ __forceinline__ void ww_epilogue(const WwArgs& p, float* smem, f32x4 (&acc)[5][3], float (&bsum)[5], bool dobias,
                                             int xi, int lane, int cb, int ci0) {
     const int l16 = lane & 15, kq = lane >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (LDS-DMA still in flight into the ring the exchange reuses)
     // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];   t[i][b] = sum_j dU[i][j] G[j][b];   dg[a][b] = sum_i G[i][a] t[i][b]
     float* sE = smem;              // [xi][16 co][WW_ESTRIDE]  (12.5 K floats, inside the stage buffers)
 #pragma unroll
@@ -327,10 +328,10 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_kernel(WwArgs p) {
             }
         };
         float a[2][5], bv[2][NNT];
-        __syncthreads();              // tile t_begin landed (vmcnt(0) is part of the barrier)
+        dma_barrier();                // tile t_begin landed
         build(b0, 0, a[0], bv[0]);
         for (int tile = t_begin; tile < t_end; ++tile) {
-            __syncthreads();          // tile + 1 landed and is visible; every wave is done with the reads of tile - 1
+            dma_barrier();            // tile + 1 landed and is visible; every wave is done with the reads of tile - 1
             const TileAddr ta = (SINDDM_WW_ABL & 1) ? tile_addr_or_null(false) : tile_addr_or_null(tile + 2 < t_end);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
@@ -572,11 +573,11 @@ __global__ __launch_bounds__(WW_THREADS) void wgrad_wino_wide_kernel(WwArgs p) {
         };
         float a[2][5], bv[2][NNT];
         f32x2 ra[5][NRA], rb[NNT][NRB];
-        __syncthreads();              // tile t_begin landed (vmcnt(0) is part of the barrier)
+        dma_barrier();                // tile t_begin landed
         load_a(b0, 0, ra); load_b(b0, 0, rb);
         comb_a(0, ra, a[0]); comb_b(0, rb, bv[0]);
         for (int tile = t_begin; tile < t_end; ++tile) {
-            __syncthreads();          // tile + 1 landed and is visible; every wave is done with the reads of tile - 1
+            dma_barrier();            // tile + 1 landed and is visible; every wave is done with the reads of tile - 1
             const TileAddr ta = next_tile(tile + 2 < t_end && !(SINDDM_WW_ABL & 1));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {              // k-step: tile columns 4j .. 4j+3 (lane group kq)
