@@ -233,3 +233,27 @@ def test_dims_with_channels_not_multiple_of_4(dim):
     assert rel_l2(xd.grad.cpu(), xc.grad) < 5e-5
     for name, p in net.named_parameters():
         assert rel_l2(p.grad.cpu(), sd[name].grad) < 3e-4, name
+
+
+@pytest.mark.parametrize("dim,B,H,W", [(160, 1, 12, 20), (160, 2, 47, 61), (160, 4, 94, 126), (160, 16, 48, 64),
+                                       (160, 16, 186, 248), (32, 3, 67, 90), (20, 2, 33, 41), (16, 5, 24, 50)])
+def test_forward_and_input_gradient_bit_reproducible(dim, B, H, W):
+    """Neither the forward nor the data gradients accumulate with atomics: the same call must return the same BITS.
+    Guards the LDS-DMA publication rule (common.h dma_barrier): a wave reading another wave's DMA
+    destination before it has landed shows up as run-to-run differences.  The shapes walk every 3x3 kernel family:
+    direct conv (dims with C % 4 != 0), first-generation Winograd, conv_wino2, conv_wino3, conv_wino4."""
+    net = _net(dim)
+    net.bind_grads()
+    x = hash_randn((B, 3, H, W), 41).to(DEV)
+    gy = hash_randn((B, 3, H, W), 42).to(DEV)
+    t = torch.tensor([(37 * i + 5) % 1000 for i in range(B)], device=DEV)
+    outs = []
+    for _ in range(3):
+        net.flat_grads.zero_()
+        xd = x.clone().requires_grad_(True)
+        y = net(xd, t, scale=1)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xd.grad.clone()))
+    for y, gx in outs[1:]:
+        assert torch.equal(y, outs[0][0])
+        assert torch.equal(gx, outs[0][1])
