@@ -14,8 +14,9 @@ ranks as independent chains and all-gathered (RCCL over xGMI):
 `style_transfer` / `harmonization` (reference main.py:296-322) drive `MultiscaleTrainer.image2image`; `roi`
 (main.py:257-294) drives `roi_guided_sampling` -- the reference picks the boxes with a cv2 GUI, here they come from
 `--roi_target y x h w` and `--roi_bbs y x h w [y x h w ...]` (finest-scale pixel coordinates).
-The CLIP-guided modes (clip_content, clip_style_*, clip_roi; main.py:153-255) need CLIP autograd and are outside
-this build.
+The CLIP-guided modes (clip_content, clip_style_*, clip_roi; main.py:153-255) are not wired to the command line: CLIP
+itself is outside this build.  Their drivers exist (`MultiscaleTrainer.clip_sampling` / `clip_roi_sampling`, the guidance
+branch of `p_mean_variance`) and take any scorer with the reference's ClipExtractor interface.
 """
 import argparse
 import os

@@ -1,9 +1,9 @@
 """MultiscaleTrainer: training loop, multi-scale sampling driver, checkpoint I/O.
 
 Mirror of reference SinDDM/trainer.py:35-285 (the hot-path part: __init__, train, sample_scales,
-save, load, step_ema, reset_parameters, Dataset).  The interactive application modes
-(image2image, clip_sampling, clip_roi_sampling, roi_guided_sampling -- trainer.py:287-488) are
-outside the MI355X hot-path build.
+save, load, step_ema, reset_parameters, Dataset) and of its application drivers (image2image, roi_guided_sampling,
+clip_sampling, clip_roi_sampling -- trainer.py:287-488; the two CLIP ones against any external scorer with the
+reference's ClipExtractor interface: CLIP itself is not part of this build).
 """
 from __future__ import annotations
 
@@ -459,5 +459,47 @@ class MultiscaleTrainer(object):
         finally:
             em.clip_guided_sampling = False
 
-    def clip_roi_sampling(self, *a, **k):
-        raise NotImplementedError('CLIP ROI sampling is outside the MI355X hot-path build')
+    def clip_roi_sampling(self, clip_model, text_input, strength, sample_batch_size, num_clip_iters=100,
+                          num_denoising_steps=2, clip_roi_bb=None, save_unbatched=False, template='lr',
+                          save_images=True):                                      # trainer.py:412-468
+        """Text-guided edit of a region of the training image: `num_clip_iters` steps of normalised gradient ascent of
+        the external score on the ROI alone (step = strength * |roi| / |grad| per sample, clamped to [-1, 1] -- plain
+        autograd on the ROI tensor, no network involved), the patch pasted back into the image, then the finest
+        scale's sampler for `num_denoising_steps` reverse steps (q_sample to t = num_denoising_steps + the HIP chain) to
+        blend it in.  Returns the final batch in [-1, 1]."""
+        em = self.ema_model
+        y0, x0, h, w = clip_roi_bb
+        top = self.n_scales - 1
+        emb = clip_model.get_text_embedding(text_input, template=template)
+        image = self.data_list[top][0][0][None].repeat(sample_batch_size, 1, 1, 1).clone()
+        roi = image[:, :, y0:y0 + h, x0:x0 + w].clone()
+        trace_dir = Path(str(em.results_folder / 'interm_samples_clip_roi'))
+        if em.save_interm:
+            trace_dir.mkdir(parents=True, exist_ok=True)
+        norm = lambda v: torch.linalg.vector_norm(v, dim=(1, 2, 3), keepdim=True)
+        for it in range(num_clip_iters):
+            roi = roi.detach().requires_grad_(True)
+            clip_model.zero_grad()
+            with torch.enable_grad():
+                score = -clip_model.calculate_clip_loss((roi + 1) * 0.5, emb)
+                grad = torch.autograd.grad(score, roi, create_graph=False)[0]
+            if em.save_interm:
+                save_image((roi.detach().clamp(-1., 1.) + 1) * 0.5, str(trace_dir / f'iter_{it}.png'), nrow=4)
+            with torch.no_grad():
+                roi = (roi + strength * (norm(roi) / norm(grad)) * grad).clamp_(-1., 1.)
+        image[:, :, y0:y0 + h, x0:x0 + w] = roi.detach()
+        final = em.sample_via_scale(sample_batch_size, image, s=top, custom_t=num_denoising_steps, scale_mul=(1, 1))
+        if save_images:
+            n_aug = getattr(clip_model, "cfg", {}).get("n_aug", 0)
+            tag = (f"clip_roi_{text_input.replace(' ', '_')}_n_aug{n_aug}_str_{strength}_n_iters_{num_clip_iters}"
+                   f'_{str(datetime.datetime.now()).replace(":", "_")}')
+            shown = (final + 1) * 0.5
+            out_dir = Path(str(em.results_folder / 'final_samples'))
+            out_dir.mkdir(parents=True, exist_ok=True)
+            save_image(shown, str(out_dir / (tag + '.png')), nrow=4)
+            if save_unbatched:
+                single_dir = Path(str(self.results_folder / f'final_samples_unbatched_{tag}'))
+                single_dir.mkdir(parents=True, exist_ok=True)
+                for b in range(sample_batch_size):
+                    save_image(shown[b], str(single_dir / f'{tag}_out_b{b}.png'))
+        return final

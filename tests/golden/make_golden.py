@@ -24,6 +24,7 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
   g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
   g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
+  g16_clip_roi.npz    trainer.clip_roi_sampling (trainer.py:412-468) with the synthetic score: ROI ascent + 5 reverse steps
   g15_clip_guided.npz CLIP-guided p_sample steps (models.py:367-431) with a SYNTHETIC differentiable score in place of
                      CLIP (clip/ is out of scope): mask creation, sub-iterations, lambda blending across steps, dim=32
   g13_roi_i2i.npz    ROI-guided p_sample steps (roi_patch_modification) and an image2image (style-transfer path,
@@ -643,7 +644,53 @@ def g15(workdir):
     save("g15_clip_guided.npz", **out)
 
 
+class SyntheticRoiScore(SyntheticScore):
+    """SyntheticScore with the two more members trainer.clip_roi_sampling touches: a config dict and a text 'embedding'
+    (an image of the ROI's size, whatever the text)."""
+    cfg = {"n_aug": 0}
+
+    def __init__(self, shape):
+        self.shape = shape
+
+    def get_text_embedding(self, text, template=None):
+        return closed_form_tensor(self.shape, phase=1.7, amp=0.35, freq=0.149) + 0.5
+
+
+def g16(workdir):
+    """trainer.clip_roi_sampling (trainer.py:412-468) through the reference: gradient ascent of an external score on a ROI
+    of the training image, the patch pasted back, a few reverse steps of the finest scale on top."""
+    cfg = CONFIGS["C1"]
+    dst, fname, sizes, losses, sf, n = run_create_img_scales(cfg, os.path.join(workdir, "G16"))
+    d = make_diffusion(ref_net(32), sizes, losses, sf, n, cfg["T"])
+    tr = rt.MultiscaleTrainer(d, folder=dst, n_scales=n, scale_factor=sf, image_sizes=sizes, train_batch_size=2,
+                              train_lr=1e-3, train_num_steps=1, gradient_accumulate_every=1, ema_decay=0.995,
+                              fp16=False, step_start_ema=1, update_ema_every=1, save_and_sample_every=10 ** 9,
+                              avg_window=1, sched_milestones=[100], results_folder=tempfile.mkdtemp(), device=DEV)
+    tr.ema_model.reblurring = True
+    B, bb, iters, steps, strength = 2, [30, 20, 40, 56], 6, 5, 0.25
+    score = SyntheticRoiScore((B, 3, bb[2], bb[3]))
+    feeder = NoiseFeeder([("renoise", n - 1, 0)] + [("step", n - 1, t) for t in reversed(range(steps))])
+    saved = []
+    o_save = rt.utils.save_image
+    rt.utils.save_image = lambda img, *a, **k: saved.append(img.detach().clone())
+    try:
+        with patched_noise(feeder):
+            tr.clip_roi_sampling(score, "a synthetic prompt", strength, B, num_clip_iters=iters,
+                                 num_denoising_steps=steps, clip_roi_bb=bb, save_unbatched=False)
+    finally:
+        rt.utils.save_image = o_save
+    save("g16_clip_roi.npz", final=saved[-1], bb=np.array(bb), iters=np.array(iters), steps=np.array(steps),
+         strength=np.array(strength))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g16":
+        workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
+        try:
+            g16(workdir)
+        finally:
+            shutil.rmtree(workdir, ignore_errors=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g15":
         workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
         try:
@@ -685,6 +732,7 @@ def main():
         g12(workdir)
         g13(workdir)
         g15(workdir)
+        g16(workdir)
         g14()
     finally:
         shutil.rmtree(workdir, ignore_errors=True)

@@ -409,3 +409,24 @@ def test_clip_guided_p_sample_golden(golden):
         assert float((d.clip_mask.cpu() != torch.from_numpy(g[f"clip_mask_s{s}"])).float().mean()) < 1e-3
         assert rel_l2(d.x_recon_prev.cpu(), g[f"x_recon_prev_s{s}"]) < 2e-5
         assert rel_l2(torch.stack([c.reshape(()) for c in d.clip_score]), g[f"clip_score_s{s}"]) < 1e-5
+
+
+def test_clip_roi_sampling_golden(golden, tmp_path):
+    """G16: MultiscaleTrainer.clip_roi_sampling (reference SinDDM/trainer.py:412-468) run by the REFERENCE with the
+    synthetic score: six steps of normalised gradient ascent on a 40x56 region of the training image, the patch pasted
+    back, then q_sample to t = 5 and five reverse steps of the finest scale (HIP chain) with the same hash noise."""
+    from sinddm_amd.synth import closed_form_tensor
+    g = golden("g16_clip_roi.npz")
+    tr, meta = _trainer(golden, tmp_path, T=100)
+    d = tr.ema_model
+    d.noise_fn = lambda kind, shape, s, t, dev: hash_randn(shape, noise_key(kind, s, t)).to(dev)
+    bb = [int(v) for v in g["bb"]]
+    score = _SyntheticScore()
+    score.emb = {"lr": (closed_form_tensor((2, 3, bb[2], bb[3]), phase=1.7, amp=0.35, freq=0.149) + 0.5).to(DEV)}
+    before = tr.data_list[meta["n_scales"] - 1][0][0].clone()
+    final = tr.clip_roi_sampling(score, "a synthetic prompt", float(g["strength"]), 2, num_clip_iters=int(g["iters"]),
+                                 num_denoising_steps=int(g["steps"]), clip_roi_bb=bb, save_unbatched=True)
+    assert rel_l2(((final + 1) * 0.5).cpu(), g["final"]) < 1e-5
+    assert torch.equal(tr.data_list[meta["n_scales"] - 1][0][0], before)          # the training image itself is untouched
+    pngs = [f for _, _, fs in os.walk(tmp_path / "res") for f in fs if f.startswith("clip_roi_") and f.endswith(".png")]
+    assert len(pngs) == 3                                                          # the grid + two unbatched images
