@@ -514,10 +514,9 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
     a.tilesY = (H + WG_TH - 1) / WG_TH;
     a.ntiles = B * a.tilesX * a.tilesY;
     constexpr int ww = SINDDM_WGRAD_WINO;
+    WwArgs w{};
+    int nwg = 0;
     if (taps == 9 && Cout % WW_CO == 0 && Cin >= 16 && ww && scr) {
-        // Winograd-domain weight gradient (2.25x fewer MFMAs); always through the [co][tap][ci] staging slab
-        if ((size_t)WW_CO * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
-        WwArgs w{};
         w.dout = dout; w.in = in; w.gw = scr; w.gb = gb;
         w.B = B; w.H = H; w.W = W; w.Cin = Cin; w.Cout = Cout;
         w.coblks = Cout / WW_CO;
@@ -525,8 +524,11 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         w.tilesX = (W + WW_TW - 1) / WW_TW;
         w.tilesY = (H + WW_TH - 1) / WW_TH;
         w.ntiles = B * w.tilesX * w.tilesY;
-        const int nwg = ww_build_map(w, device_cu_count());
-        if (nwg <= 0) return SINDDM_E_BADSHAPE;
+        nwg = ww_build_map(w, device_cu_count());      // 0: more slabs than the launch table holds -> the direct kernels below
+    }
+    if (nwg > 0) {
+        // Winograd-domain weight gradient (2.25x fewer MFMAs); always through the [co][tap][ci] staging slab
+        if ((size_t)WW_CO * H * W * 4 >= 0x40000000ull) return SINDDM_E_BADSHAPE;
         const int n = Cout * Cin * 9;
         hipError_t e = hipMemsetAsync(scr, 0, (size_t)n * sizeof(float), st);
         if (e != hipSuccess) return (int)e;

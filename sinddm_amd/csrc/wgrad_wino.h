@@ -51,7 +51,7 @@ constexpr int WW_ESTRIDE = WW_CI + 1;                // epilogue exchange [xi][1
 // MFMAs (with one S for all slabs the 16-channel slab's workgroups idled for two thirds of the launch: 0.83 of the CUs'
 // time used).  Entry = slab << 16 | split; workgroups are ordered by the start of their tile range and dealt to the XCDs
 // in contiguous runs, so the workgroups that stream the same dY / input tiles at the same time share an L2.
-constexpr int WW_MAXWG = 512, WW_MAXSLAB = 64;
+constexpr int WW_MAXWG = 512, WW_MAXSLAB = 256;       // (2.5 KB of kernel arguments)
 struct WwMap {
     unsigned wg[WW_MAXWG];
     unsigned short S[WW_MAXSLAB];

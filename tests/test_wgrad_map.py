@@ -17,7 +17,7 @@ WW_CI, WW_CO = 48, 80
 def _map(cin, cout, ntiles, ncu):
     lib = _lib.load()
     wg = (C.c_uint32 * 512)()
-    sp = (C.c_int32 * 64)()
+    sp = (C.c_int32 * 256)()
     n = lib.sinddm_debug_wgrad_map(cin, cout, ntiles, ncu, wg, sp)
     return n, list(wg[:max(n, 0)]), list(sp)
 
@@ -62,4 +62,5 @@ def test_small_launches_and_bad_arguments():
     n, wg, sp = _map(160, 160, 3, 256)          # fewer tiles than CUs: no slab gets more splits than tiles
     assert n > 0 and all(v <= 3 for v in sp[:8])
     assert _map(160, 100, 100, 256)[0] < 0      # Cout not a multiple of the 80-channel slab
-    assert _map(48 * 70, 80, 100, 256)[0] < 0   # more slabs than the table holds
+    assert _map(48 * 70, 80, 100, 256)[0] > 0   # 70 slabs: one workgroup each at least
+    assert _map(48 * 300, 80, 100, 256)[0] < 0  # more slabs than the table holds
