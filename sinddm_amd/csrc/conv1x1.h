@@ -290,52 +290,42 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
                 if constexpr (ACT == 2) uv[slot][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_aux, (int)o, 0, 0));
             }
         };
-        // TAIL builds (H*W % 4 != 0): only the last tile of an image has lanes whose 4 pixels straddle the end of a plane;
-        // it takes the scalar path (a wave-uniform branch), every other tile the 16-byte one
+        // TAIL builds (H*W % 4 != 0): in the last tile of an image ONE lane's 4 pixels straddle the end of a plane.  Its
+        // 16-byte store is sent out of range and its 1..3 valid pixels are written through plain pointers behind a
+        // per-lane branch (one wave per image diverges); operand LOADS may run into the next plane (still inside the
+        // tensor, or clipped by the descriptor): the values they feed are never stored.  (Round 2's separate scalar path
+        // for the whole tile spilled 80 registers; masked 4-byte BUFFER stores behind the dropped 16-byte one left pixels
+        // 1 and 2 of the quad wrong on the hardware -- from builtins and from asm alike, unexplained.)
         const bool tail_tile = TAIL && p0 + C1_PIX > HW;
-        if (!tail_tile) {
-            fetch(0, 0);
+        const int keep = TAIL ? HW - px0 : 4;                     // >= 4: whole quad inside; 1..3: straddling; <= 0: outside
+        const bool straddle = TAIL && keep > 0 && keep < 4;
+        fetch(0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) {
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
-                if (mt + 1 < MTT) fetch(mt + 1, (mt + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int mt = 0; mt < MTT; ++mt) {
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
+            if (mt + 1 < MTT) fetch(mt + 1, (mt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f32x4 v{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
-                    v += bias4[r];
-                    if constexpr (ACT == 1) {
+            for (int r = 0; r < 4; ++r) {
+                f32x4 v{acc[mt][0][r], acc[mt][1][r], acc[mt][2][r], acc[mt][3][r]};
+                v += bias4[r];
+                if constexpr (ACT == 1) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-                    } else if constexpr (ACT == 2) {
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if constexpr (ACT == 2) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(uv[mt & 1][r][j]);
-                    }
-                    if constexpr (RES) v += rv[mt & 1][r];
-                    if (C1B_ABL & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.4f) p.out[tid] = v[1]; continue; }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off[mt & 1][r], 0, 0);
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(uv[mt & 1][r][j]);
                 }
-            }
-        } else {
+                if constexpr (RES) v += rv[mt & 1][r];
+                if (C1B_ABL & 4) { if (v[0] + v[1] + v[2] + v[3] == 123.4f) p.out[tid] = v[1]; continue; }
+                const unsigned o = off[mt & 1][r];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)(straddle ? OOB : o), 0, 0);
+                if (tail_tile && straddle) {             // (one lane of the image's last tile)
+                    float* q = p.out + samp + (size_t)(co0 + mt * 16 + kq * 4 + r) * HW + px0;
 #pragma unroll
-            for (int mt = 0; mt < MTT; ++mt) {
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mt * 16 + kq * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + mt * 16 + kq * 4 + r;           // (< C_out by construction)
-                    const size_t o = samp + (size_t)co * HW + px0;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (px0 + j < HW) {
-                            float w = acc[mt][j][r] + bias4[r];
-                            if constexpr (ACT == 1) w = gelu_erf(w);
-                            else if constexpr (ACT == 2) w *= gelu_erf_grad(p.aux[o + j]);
-                            if constexpr (RES) w += p.resid[o + j];
-                            p.out[o + j] = w;
-                        }
-                    }
+                    for (int j = 0; j < 3; ++j)
+                        if (j < keep) q[j] = v[j];
                 }
             }
         }
@@ -345,12 +335,17 @@ __global__ __launch_bounds__(C1_THREADS, 2) void conv1x1_all_kernel(ConvArgs p, 
 
 template <int MTT>
 inline void conv1x1_all_launch(const ConvArgs& a, int tpi, int ntiles, hipStream_t st) {
-    // (H*W % 4 != 0 stays on the first-generation kernel: the TAIL = 1 instantiation measured no faster -- 80+ spilled
-    // registers around its scalar tail path)
+    // (H*W % 4 != 0: the TAIL = 1 instantiation -- the one straddling lane of an image's last tile stores element-wise)
     const size_t lds = ((size_t)((a.Cin2 + 15) / 16 * 4) * MTT * 64 + MTT * 16) * sizeof(float);   // k-steps padded to 4, + bias
     const int cus = 256;
     const dim3 grid((unsigned)(ntiles < 2 * cus ? ntiles : 2 * cus), (unsigned)(a.Cout / (MTT * 16)));
-#define C1B_GO(ACT, RES) hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), grid, dim3(C1_THREADS), lds, st, a, tpi, ntiles)
+#define C1B_GO(ACT, RES)                                                                                                \
+    do {                                                                                                                \
+        if ((a.H * a.W) % 4 == 0)                                                                                       \
+            hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 0, RES>), grid, dim3(C1_THREADS), lds, st, a, tpi, ntiles); \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv1x1_all_kernel<MTT, ACT, 1, RES>), grid, dim3(C1_THREADS), lds, st, a, tpi, ntiles); \
+    } while (0)
     const int res = a.resid != nullptr;
     switch ((a.act & 0xff) * 2 + res) {
         case 0: C1B_GO(0, 0); break;
@@ -365,6 +360,9 @@ inline void conv1x1_all_launch(const ConvArgs& a, int tpi, int ntiles, hipStream
 
 #ifndef SINDDM_CONV1X1_V2
 #define SINDDM_CONV1X1_V2 1
+#endif
+#ifndef SINDDM_CONV1X1_TAIL   // 1: H*W % 4 != 0 on the second-generation kernel too (TAIL instantiation)
+#define SINDDM_CONV1X1_TAIL 1
 #endif
 
 inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
@@ -382,7 +380,7 @@ inline int conv1x1_launch(const ConvArgs& a, int mt, hipStream_t st) {
     const int tpi = (HW + C1_PIX - 1) / C1_PIX;
     const dim3 grid((unsigned)(a.B * tpi), (unsigned)a.coblks);
     const int mtt = mt * a.coblks;
-    if (SINDDM_CONV1X1_V2 && mt == 5 && (mtt == 5 || mtt == 10) && a.Cout == mtt * 16 && HW % 4 == 0 && a.Cin2 <= 160) {
+    if (SINDDM_CONV1X1_V2 && mt == 5 && (mtt == 5 || mtt == 10) && a.Cout == mtt * 16 && (SINDDM_CONV1X1_TAIL || HW % 4 == 0) && a.Cin2 <= 160) {
         const int ntiles = a.B * tpi;
         // enough pixel tiles to fill the chip: every workgroup computes all output channels (input read once);
         // fewer: the channels are split over workgroups -- 80 per workgroup, then 16 (coarse scales at small batch)
