@@ -532,12 +532,21 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
             }
     float* dst = out + (size_t)b * Cout * HW + pc;
     float* dpre = out_pre ? out_pre + (size_t)b * Cout * HW + pc : nullptr;
+    // taps in pairs: (v[2j], v[2j+1]) * (w[2j], w[2j+1]) is ONE v_pk_fma_f32 with the weight pair as a scalar operand --
+    // 13 packed + 1 plain FMA + 1 add instead of 27 FMAs per output; the kernel is VALU-bound (27 taps + GELU per output)
+    f32x2 vp[13];
+#pragma unroll
+    for (int j = 0; j < 13; ++j) vp[j] = f32x2{v[2 * j], v[2 * j + 1]};
 #pragma unroll 4
     for (int co = co0; co < co1; ++co) {
         const float* wc = w + co * 27;          // wave-uniform -> scalar loads
-        float acc = bias[co];
+        f32x2 acc2{bias[co], 0.f};
 #pragma unroll
-        for (int k = 0; k < 27; ++k) acc = fmaf(v[k], wc[k], acc);
+        for (int j = 0; j < 13; ++j) {
+            const f32x2 wp{wc[2 * j], wc[2 * j + 1]};
+            acc2 = __builtin_elementwise_fma(vp[j], wp, acc2);
+        }
+        const float acc = fmaf(v[26], wc[26], acc2.x + acc2.y);
         if (live) {
             if (dpre) dpre[(size_t)co * HW] = acc;
             dst[(size_t)co * HW] = gelu_erf(acc);
