@@ -108,8 +108,14 @@ class Ctx:
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         self.comm_world = 1
-        if self.world > 1:
+        # SINDDM_BENCH_FORCE_DIST=1: create the process group and run every timing / gather collective even with ONE
+        # rank, so that the RCCL code path the 2/4/8-GPU runs take is executed on a 1-GPU box (tests/test_gpu_rccl.py)
+        self.dist_on = self.world > 1 or os.environ.get("SINDDM_BENCH_FORCE_DIST", "0") == "1"
+        if self.dist_on:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             if self.backend == "nccl":
                 td.init_process_group(backend="nccl", device_id=self.dev)
             else:
@@ -118,19 +124,19 @@ class Ctx:
             assert self.comm_world == self.world
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist_on:
             self.td.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(self, v: float) -> float:
-        if self.world == 1:
+        if not self.dist_on:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
         return float(t)
 
     def min_over_ranks(self, v: float) -> float:
-        if self.world == 1:
+        if not self.dist_on:
             return v
         t = torch.tensor([v], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.td.all_reduce(t, op=self.td.ReduceOp.MIN)
@@ -138,7 +144,7 @@ class Ctx:
 
     def gather_shards(self, cur, sizes):
         """all-gather of uneven batch shards (strong scaling): pad to the largest shard, gather, cut."""
-        if self.world == 1:
+        if not self.dist_on:
             return cur
         bmax = max(sizes)
         pad = cur
@@ -148,14 +154,14 @@ class Ctx:
         return torch.cat([out[r * bmax:r * bmax + b] for r, b in enumerate(sizes)])
 
     def gather(self, cur, B):
-        if self.world == 1:
+        if not self.dist_on:
             return cur
         if self.backend == "nccl":
             out = torch.empty((self.world * B,) + tuple(cur.shape[1:]), device=self.dev)
             self.td.all_gather_into_tensor(out, cur.contiguous())
             return out
         from sinddm_amd import dist as sdist
-        return sdist.gather_batch(cur.cpu(), self.world * B).to(self.dev)
+        return sdist.gather_batch(cur.cpu(), self.world * B, force=True).to(self.dev)
 
 
 def _prof(lib, kind, reset):
@@ -198,12 +204,23 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     if warmup:
         img = d._run_steps(img, s, t_seq[:warmup])
     ctx.barrier()
-    lib.sinddm_prof_begin()
     t0 = time.perf_counter()
     img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
     ctx.barrier()
     dt = time.perf_counter() - t0
+    # the headline region above carries no instrumentation; the roofline comes from a SECOND, untimed pass over the same
+    # steps with HIP events around every MFMA conv launch (on the launch stream)
+    lib.sinddm_prof_begin()
+    t0p = time.perf_counter()
+    img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
+    ctx.barrier()
+    dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
+    mix = {}
+    for gen, name in ((4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"), (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
+        g_ms, g_n, _, _ = _prof(lib, 10 + gen, 0)
+        if g_n:
+            mix[name] = {"launches": int(g_n), "avg_launch_ms": round(g_ms / g_n, 4)}
     all_ms, all_n, all_fl, all_ex = _prof(lib, 0, 1)          # every MFMA convolution of the step
     dt_rank = dt
     dt = ctx.max_over_ranks(dt_rank)
@@ -216,8 +233,11 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     traffic, traffic_src = _traffic(cfg_name)
     roofline = {
         "bound": "mfma",
-        "kernel": "conv_wino4_kernel<*> (Winograd F(2x4,3x3) 3x3 conv on v_mfma_f32_16x16x4_f32, one wave per SIMD, "
-                  "two n-tiles per wave; 7 launches per step; launches below 2 work items per CU: conv_wino3 / conv_wino2)",
+        "kernel": "Winograd 3x3 conv family on v_mfma_f32_16x16x4_f32 (7 launches per step); this run's launches by kernel: "
+                  + ", ".join(f"{k} x{v['launches']}" for k, v in mix.items()),
+        "kernel_mix": mix,
+        "measured_in": "second, untimed pass over the same steps with HIP events around each launch "
+                       f"({round(dt_prof / steps * 1e3, 4)} ms/step with the events on)",
         "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic, "traffic_source": traffic_src,
@@ -231,9 +251,9 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
         # for comparison with earlier rounds' `frac` -- the F(2x4) kernel executes 24/72 and `frac` above counts that
         "frac_if_counted_as_f2x2": round(algorithmic * (16.0 / 36.0) / FP32_MFMA_PEAK_TFLOPS, 4),
         "avg_launch_ms": round(avg_launch_ms, 4), "launches": int(dom_n),
-        "share_of_step": round(dom_ms / (dt * 1e3), 4),
+        "share_of_step": round(dom_ms / (dt_prof * 1e3), 4),
         "all_mfma_convs": {"algorithmic_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2) if all_ms > 0 else 0.0,
-                           "launches": int(all_n), "share_of_step": round(all_ms / (dt * 1e3), 4)},
+                           "launches": int(all_n), "share_of_step": round(all_ms / (dt_prof * 1e3), 4)},
         "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * steps / dt / 1e12, 2),
     }
     G = global_batch if global_batch is not None else ctx.world * B
@@ -316,7 +336,7 @@ def full_sample_leg(ctx, d, cfg, B, sizes=None):
                           "mpx_steps_per_sec": round(B * h * w * d.num_timesteps_ideal[si] / dts / 1e6, 1)})
     return {"imgs_per_sec": round(total / ft, 4), "seconds": round(ft, 3), "images": total,
             "per_scale_this_rank": per_scale,
-            "all_gather_seconds": round(tg, 6) if ctx.world > 1 else 0.0,
+            "all_gather_seconds": round(tg, 6) if ctx.dist_on else 0.0,
             "net_evals_per_image": sum(d.num_timesteps_ideal),
             "net_tflops": round(NET_FLOP_PER_PIXEL * pix_steps * total / ft / 1e12, 2),
             "finite": bool(torch.isfinite(cur).all())}
@@ -373,7 +393,7 @@ def train_leg(ctx, steps=5, warmup=2):
     if cv_n:
         ex = cv_ex / (cv_ms * 1e-3) / 1e12
         rec["conv_roofline"] = {
-            "kernel": "conv_wino4_kernel (forward + both data gradients)", "launches_per_step": cv_n,
+            "kernel": "Winograd 3x3 conv family (forward + both data gradients)", "launches_per_step": cv_n,
             "ms_per_step": round(cv_ms, 3), "share_of_step": round(cv_ms / (dt * 1e3), 4),
             "achieved": round(ex, 2), "frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4)}
     return rec
@@ -516,7 +536,7 @@ def main():
         }
         line.update(nested)
         print(json.dumps(line), flush=True)
-    if ctx.world > 1:
+    if ctx.dist_on:
         ctx.td.destroy_process_group()
 
 

@@ -8,6 +8,7 @@
 #ifndef SINDDM_HIP_DEBUG_H
 #define SINDDM_HIP_DEBUG_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -26,9 +27,25 @@ int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv
                      double* conv_exec_flops_total);
 /* Same, restricted to one kernel family: kind 0 = all, 1 = Winograd 3x3 (conv_wino2/3/4/5_kernel), 2 = 1x1 convs,
  * 3 = direct 3x3 (conv_mfma_dma_kernel), 4 = Winograd-domain 3x3 weight gradient (wgrad_wino_kernel, F(2x2): 16/36 of
- * 2*B*H*W*Cout*Cin*9 executed).  reset = 0 keeps the records so that several kinds can be queried. */
+ * 2*B*H*W*Cout*Cin*9 executed); 11 .. 14 = the Winograd 3x3 launches of ONE kernel generation (conv_wino, conv_wino2,
+ * conv_wino3, conv_wino4).  reset = 0 keeps the records so that several kinds can be queried. */
 int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total,
                      double* exec_flops_total, int reset);
+
+/* Which kernel generation the dim -> dim 3x3 convolutions of a launch of this shape take on the current device:
+ * 4 = conv_wino4 (F(2x4,3x3), one wave per SIMD), 3 = conv_wino3 (F(2x4,3x3)), 2 = F(2x2,3x3) kernels, 0 = direct
+ * implicit GEMM; negative = SINDDM_E_*.  Lets a test assert that it exercises the kernel it means to. */
+int sinddm_debug_conv_path(int dim, int B, int H, int W);
+
+/* ONE SinDDMConvBlock (l = 0..3 of the plan of SinDDMNet(dim); reference SinDDM/models.py:51-80) forward + backward on
+ * its own: x (B, C_in, H, W), cond_bias (B, C_in) = the block's per-sample condition (time_reshape(mlp(cond)),
+ * models.py:74-76), grad_y (B, C_out, H, W).  Writes y, grad_x (may be NULL), dcond (B, C_in) = gradient of cond_bias, and
+ * ADDS the block's conv / depthwise weight and bias gradients into grad_params (flat layout of sinddm_param_offset).
+ * ws: a training workspace (sinddm_train_workspace_bytes).  For block-level parity tests; training never calls it. */
+int sinddm_debug_block_train(const float* params, const float* packed, const float* packed_bwd, int dim, int l,
+                             const float* x, const float* cond_bias, const float* grad_y, float* y, float* grad_x,
+                             float* grad_params, float* dcond, int B, int H, int W, void* ws, size_t ws_bytes,
+                             void* stream);
 
 /* Host-only (no device call): the workgroup -> (slab, pixel split) table wgrad_wino_kernel would be launched with for a
  * Cin -> Cout 3x3 weight gradient over `ntiles` 4x16-pixel tiles on `ncu` compute units.  wg_out (>= 512 entries) receives

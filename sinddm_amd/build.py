@@ -90,9 +90,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 print("[sinddm_amd.build]", " ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
             objs.append(obj)
-        for cmd, pr in procs:
-            if pr.wait() != 0:
-                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        failed = None
+        try:
+            for cmd, pr in procs:
+                if pr.wait() != 0 and failed is None:
+                    failed = (pr.returncode, cmd)
+                    break
+        finally:
+            # never leave a compiler writing into the temporary directory that is about to be deleted
+            for _, pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                pr.wait()
+        if failed:
+            raise subprocess.CalledProcessError(*failed)
         link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", LIB]
         if verbose:
             print("[sinddm_amd.build]", " ".join(link), flush=True)

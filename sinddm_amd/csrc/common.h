@@ -18,10 +18,6 @@ namespace sinddm {
 #ifndef SINDDM_WINO_V4        // 1: launches with several 8x32 items per CU on the one-wave-per-SIMD F(2x4,3x3) kernel (conv_wino4.h)
 #define SINDDM_WINO_V4 1
 #endif
-#ifndef SINDDM_WINO_V5        // 1: those launches on conv_wino5.h (two waves per SIMD, half a frequency row each) instead of conv_wino4.h;
-                              // measured equal to 1 % slower on C2 / C3, kept as the two-wave reference
-#define SINDDM_WINO_V5 0
-#endif
 #ifndef SINDDM_CONV_WINO      // 1: 3x3 convs (C_in >= 8) on the Winograd kernel, 0: direct implicit-GEMM kernel
 #define SINDDM_CONV_WINO 1
 #endif

@@ -289,9 +289,10 @@ struct ConvProfiler {
     int created = 0;
     // per record: which kernel family (1 = Winograd 3x3, 2 = 1x1, 3 = direct 3x3) and its FLOP counts
     unsigned char kind[MAXREC];
+    unsigned char gen[MAXREC];   // Winograd launches: kernel generation (4 = conv_wino4, 3 = conv_wino3, 2 = conv_wino2, 1 = conv_wino)
     double rec_flops[MAXREC], rec_exec[MAXREC];
-    void note(int k, double fl, double ex) {
-        kind[used] = (unsigned char)k; rec_flops[used] = fl; rec_exec[used] = ex;
+    void note(int k, double fl, double ex, int g = 0) {
+        kind[used] = (unsigned char)k; gen[used] = (unsigned char)g; rec_flops[used] = fl; rec_exec[used] = ex;
         flops += fl; exec_flops += ex; ++used;
     }
 };

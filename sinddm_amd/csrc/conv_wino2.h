@@ -705,7 +705,7 @@ inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
-        prof.note(1, fl, fl * (16.0 / 36.0));
+        prof.note(1, fl, fl * (16.0 / 36.0), 2);
     }
     SINDDM_LAUNCH_CHECK();
     return 0;

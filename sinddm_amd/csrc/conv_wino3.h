@@ -33,8 +33,8 @@ constexpr int W3_KS_BYTES = W3_Q * 1024;       // weights of one (i, k-step)
 constexpr int W3_CH_BYTES = 4 * 4 * W3_KS_BYTES;   // ... of one 16-channel chunk (4 waves x 4 k-steps)
 // Order of a (row i, k-step)'s 30 A fragments in the packed image (round 3): 32 four-byte slots per lane = two halves of
 // 16; half MH holds m-tiles MH and 2 + MH (six frequencies each) and frequencies 3 MH .. 3 MH + 2 of m-tile 4, its slot 15
-// is padding.  conv_wino5.h gives a half to each of the two waves of a SIMD (four consecutive 16-byte groups per wave);
-// the kernels that keep a whole row in one wave walk the slots in this order too.  Returns e = m-tile * 6 + frequency, or
+// is padding (the order a two-waves-per-SIMD kernel of round 3 needed -- a half per wave; that kernel is gone, the image
+// stayed).  conv_wino3 / conv_wino4 walk the slots in this order.  Returns e = m-tile * 6 + frequency, or
 // -1 for padding.
 constexpr int w3_pos_e(int pos) {
     const int mh = pos >> 4, el = pos & 15;
@@ -445,7 +445,7 @@ inline int conv_wino3_launch(const ConvArgs& a_in, hipStream_t st) {
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
-        prof.note(1, fl, fl * (24.0 / 72.0));                                      // F(2x4): 24 multiplies per 8 outputs
+        prof.note(1, fl, fl * (24.0 / 72.0), 3);                                      // F(2x4): 24 multiplies per 8 outputs
     }
     SINDDM_LAUNCH_CHECK();
     return 0;

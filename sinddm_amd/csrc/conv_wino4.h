@@ -50,6 +50,7 @@ __device__ __forceinline__ void w4_static_for(F&& f) {
 
 // Compile-time timing ablations (-DW4_ABL=bits; results are WRONG, never ship):
 //   1 no raw-tile staging   2 weights loaded once   4 no raw-patch LDS reads   8 no epilogue   16 no input transform
+//   256 epilogue without global loads / stores (2048: without the loads, 4096: without the stores)   512 ... without its LDS writes   1024 ... without its LDS reads
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -78,6 +79,12 @@ __device__ unsigned long long g_w4_ks[8 * 256 * 4 * 64];
 #define W4_PF_KS 3            // k-step / slot of a chunk in which the epilogue's pass-0 operands are requested (slot -1: at the
 #define W4_PF_SLOT 58         // top of the epilogue instead).  Late in the LAST chunk: what is queued behind these loads
 #endif                        // (vector memory returns in order) is only needed after the epilogue
+#ifndef W4_PF_AHEAD
+#define W4_PF_AHEAD 1         // the epilogue's per-pass operands (residual / pre-activation, bias) are requested this many passes
+#endif                        // ahead of their use (register sets: W4_PF_AHEAD + 1); the first W4_PF_AHEAD passes inside the last chunk
+#ifndef W4_STAGGER
+#define W4_STAGGER 0          // > 0: the workgroups start in this many phases, spread over one work-item time -- with every CU in
+#endif                        // lock step all 256 epilogues hit HBM at the same moment (see the launch code)
 #ifndef W4_XF_SLOT
 #define W4_XF_SLOT 40          // the slot of a k-step behind whose MFMA the input-transform burst of the next k-step sits
 #endif
@@ -86,19 +93,20 @@ __device__ unsigned long long g_w4_ks[8 * 256 * 4 * 64];
 // chunk iteration paid 300-500 v_accvgpr copies to undo the permutation at the loop back edge.)  The compiler never
 // allocates an AGPR in this kernel -- it sees no MFMA and spills nothing -- and learns the count from the clobber
 // list of w4_acc_declare(); `tests/test_build_isa.py` checks that every AGPR access in the ISA is one of these asms.
-template <int T>
+// ZC: the accumulator input is the constant 0 -- the first k-step of a work item starts its sums that way, so the 240
+// registers are never zeroed (240 v_accvgpr_write per wave and item in round 3)
+template <int T, bool ZC>
 __device__ __forceinline__ void w4_mfma(float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * T), "n"(4 * T + 3));
+    if constexpr (ZC)
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, 0" ::"v"(a), "v"(b), "n"(4 * T), "n"(4 * T + 3));
+    else
+        asm volatile("v_mfma_f32_16x16x4_f32 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * T), "n"(4 * T + 3));
 }
 template <int R>
 __device__ __forceinline__ float w4_acc_read() {
     float r;
     asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(r) : "n"(R));
     return r;
-}
-template <int R>
-__device__ __forceinline__ void w4_acc_zero() {
-    asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"n"(R));
 }
 __device__ __forceinline__ void w4_acc_declare() { asm volatile("" ::: "a0", "a239"); }
 
@@ -115,8 +123,10 @@ constexpr int W4_PS = 411;                    // LDS plane stride (10 x 41 = 410
 constexpr int W4_BUF = 8192;                  // floats per raw-tile buffer: 16 planes (6 576) padded to 32 KB -- a power of two, so that
                                               // the two buffers swap by XOR of every LDS address register with 0x8000
 static_assert(16 * W4_PS <= W4_BUF, "raw-tile buffer");
-constexpr int W4_XCH = 4 * 32 * 32 * 4;       // exchange area: [i][32 channels][32 tiles][4 columns]
-constexpr int W4_LDS_FLOATS = 2 * W4_BUF + W4_XCH;
+constexpr int W4_XB = 4 * 4 * 32 * 16;        // one exchange buffer: an m-tile's column-transformed values, [i][column][32 tiles][16 channels]
+constexpr int W4_XCH = 2 * W4_XB;             // two of them: m-tile p + 1 is written while p is read
+constexpr int W4_LDS_FLOATS = 2 * W4_BUF + W4_XCH;   // 64 + 64 KB
+static_assert(W4_LDS_FLOATS * 4 <= 160 * 1024, "LDS of a gfx950 CU");
 static_assert((2 * W4_BUF) % 4 == 0, "exchange area must stay 16-byte aligned");
 
 struct Wino4Item {
@@ -124,7 +134,7 @@ struct Wino4Item {
 };
 
 template <int ACT, int EDGE>
-__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
+__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd, int stagger) {
     constexpr int MT = W3_MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sX = smem + 2 * W4_BUF;
@@ -270,6 +280,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     // 18 v_pk_*_f32 in one burst 7 each.  So the two n-tiles are transformed together, (n-tile 0, n-tile 1) in the halves
     // of a register pair: 18 packed instructions per k-step, in ONE block between two MFMAs.
     const f32x2 sgn2{sgn, sgn};
+    f32x2 n1{-1.f, -1.f};                           // opaque to the optimiser (see the epilogue)
+    asm volatile("" : "+v"(n1));
+    const f32x4 n4{n1.x, n1.y, n1.x, n1.y};
     auto xf_burst = [&](f32x2 (&ra)[6], f32x2 (&rb)[6], f32x2 (&v)[W3_NF], int nvalid) __attribute__((always_inline)) {
         // (pins: everything below stays behind this point -- the loads have landed -- and in front of the next MFMA)
         asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]));
@@ -306,7 +319,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     int l = 0;
     if (!decode(l, it)) return;
     w4_acc_declare();
-    w4_static_for<2 * MT * W3_NF * 4>([&](auto R) __attribute__((always_inline)) { w4_acc_zero<decltype(R)::value>(); });
+    if (W4_STAGGER > 0 && stagger > 0) {
+        // start phase of this workgroup: pairs of neighbours (the two 80-channel blocks of a tile) stay together
+        const unsigned long long t_go = __builtin_amdgcn_s_memtime() + (unsigned long long)((ls >> 1) % W4_STAGGER) * (unsigned)stagger;
+        while (__builtin_amdgcn_s_memtime() < t_go) __builtin_amdgcn_s_sleep(16);
+    }
     make_goff(it);
     nv = nvn;
     int wb_it = wbase(it.cb);
@@ -341,10 +358,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     }
     xf_burst(raw[0], raw[1], v[0], nv);
 
-    // ---- epilogue reader role: thread = 2x4 tile (n-tile, tile row, tile column) x channels cg + 8 k of a pass ----
-    const int tile = tid & 31;
+    // ---- epilogue reader role: thread = 2x4 tile (n-tile, tile row, tile column) x TWO consecutive channels (half `hf` of
+    // quad kqr of the pass's m-tile).  An accumulator tile's four registers are four consecutive channels, so the
+    // exchange area is channel-minor: 16-byte pieces on the way in (writer lane (l16, kq): 1 KB contiguous per wave and
+    // instruction), 8-byte pieces on the way out (reader lanes (hf, kqr, tile): 512 B contiguous) -- conflict-free both ways
+    const int hf = tid & 1, kqr = (tid >> 1) & 3;
+    const int tile = tid >> 3;
     const int hr = tile >> 4, trr = (tile >> 3) & 1, tcr = tile & 7;
-    const int cg = tid >> 5;
+    const int cg = kqr * 4 + hf * 2;              // first of the thread's two channels inside the m-tile
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
     // a 4-pixel output quad goes out in NP pieces: one 16-byte access, or at images with W % 4 != 0 two 8-byte / four
@@ -370,7 +391,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     };
     unsigned vo[2][NP], vo_nx[2][NP];
     ep_geo(it, vo);
-    auto ep_in_block = [](int m0, int k) { return m0 * 16 + 8 * k + 8 <= MT * 16; };
     auto ep_load = [&](const __amdgpu_buffer_rsrc_t& r, int pp, int soff) __attribute__((always_inline)) -> f32x4 {
         if constexpr (EE == 0) {
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[pp][0], soff, 0));
@@ -387,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         }
     };
     auto ep_store = [&](const __amdgpu_buffer_rsrc_t& r, int pp, int soff, f32x4 vv) __attribute__((always_inline)) {
+        if (W4_ABL & (256 | 4096)) { asm volatile("" ::"v"(vv)); return; }
         const u32x4 u = __builtin_bit_cast(u32x4, vv);
         if constexpr (EE == 0) {
             // (store + one wait state as ONE asm: a 16-byte buffer store reads its data registers after it has issued,
@@ -403,8 +424,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         }
     };
     // two register sets of pass operands: a pass computes from one while the next pass's arrive in the other
-    f32x4 opv[2][4][2];
-    float bsv[2][4];
+    constexpr int NS = W4_PF_AHEAD + 1;
+    f32x4 opv[NS][2][2];                            // [set][channel][output row]
+    f32x2 bsv[NS];                                  // [set] bias of the two channels
+    // the lane's slot in its wave's window of an exchange buffer (writer side) and the thread's (reader side)
+    float* xwrite = sX + (wi * 4 * 32 + l16) * 16 + kq * 4;
+    const float* xread = sX + tile * 16 + kqr * 4 + hf * 2;
 
     for (;;) {
 #ifdef W4_TIMING
@@ -433,23 +458,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.zero), 0, 0u, 0x00020000);
         const int cb_ch = it.cb * (MT * 16);
-        auto ep_soff = [&](int m0, int k) -> int { return (cb_ch + m0 * 16 + 8 * k) * (int)plane_b; };
-        // operands of one pass into register set SET: per channel k the bias and, per output row, the residual (ACT 0 / 1)
-        // or the pre-activation whose GELU' multiplies the result (ACT 2; the data-gradient convs carry no residual)
+        auto ep_soff = [&](int m0, int r) -> int { return (cb_ch + m0 * 16 + r) * (int)plane_b; };
+        // operands of one pass (= m-tile m0) into register set SET: the bias of the thread's two channels and, per channel
+        // and output row, the residual (ACT 0 / 1) or the pre-activation whose GELU' multiplies the result (ACT 2; the
+        // data-gradient convs carry no residual)
         auto ep_fetch = [&](auto SET, int m0, const __amdgpu_buffer_rsrc_t& rop, const __amdgpu_buffer_rsrc_t& rbias)
                             __attribute__((always_inline)) {
             constexpr int set = decltype(SET)::value;
+            if (W4_ABL & (256 | 2048)) return;
+            if (ACT != 2)
+                bsv[set] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rbias, cg * 4, (cb_ch + m0 * 16) * 4, 0));
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!ep_in_block(m0, k)) continue;
-                if (ACT != 2)
-                    bsv[set][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rbias, cg * 4, (cb_ch + m0 * 16 + 8 * k) * 4, 0));
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int pp = 0; pp < 2; ++pp) opv[set][k][pp] = ep_load(rop, pp, ep_soff(m0, k));
-            }
+                for (int pp = 0; pp < 2; ++pp) opv[set][r][pp] = ep_load(rop, pp, ep_soff(m0, r));
         };
-        for (int c = 0; c < nch; ++c) {
+        auto chunk = [&](int c, auto ZC) __attribute__((always_inline)) {
+            constexpr bool zc = decltype(ZC)::value;     // the item's first chunk: its k-step 0 starts the sums (C = 0)
 #ifdef W4_KSTAMP
             const bool kst = l == 4 && c == 2 && blockIdx.x < 256;
 #endif
@@ -491,8 +516,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     constexpr int pos = idx + (idx >= 15 ? 1 : 0);          // slot of the packed order (15 and 31 are padding)
                     constexpr int e = w3_pos_e(pos);
                     constexpr int mt = e / W3_NF, j = e - mt * W3_NF;
-                    if constexpr ((pos >> 2 & 3) != 3) w4_mfma<(h * MT + mt) * W3_NF + j>(aq[ks & 1][pos >> 2][pos & 3], v[ks & 1][j][h]);
-                    else w4_mfma<(h * MT + mt) * W3_NF + j>(aq3[ks & 1][pos >> 4][pos & 3], v[ks & 1][j][h]);
+                    if constexpr ((pos >> 2 & 3) != 3) w4_mfma<(h * MT + mt) * W3_NF + j, zc && ks == 0>(aq[ks & 1][pos >> 2][pos & 3], v[ks & 1][j][h]);
+                    else w4_mfma<(h * MT + mt) * W3_NF + j, zc && ks == 0>(aq3[ks & 1][pos >> 4][pos & 3], v[ks & 1][j][h]);
                     // raw-patch reads of the next k-step: slots 0..23
                     if constexpr (s < 24 && !(W4_ABL & 4)) {
                         constexpr int hh = s & 1, m = s >> 1, cc = m >> 1, wh = m & 1;
@@ -525,6 +550,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) {
                         if (last) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_op, rs_bias);
                     }
+                    if constexpr (W4_PF_AHEAD >= 2 && ks == W4_PF_KS && s == W4_PF_SLOT - 28 && !(W4_ABL & 8)) {
+                        if (last) ep_fetch(std::integral_constant<int, 1>{}, 1, rs_op, rs_bias);
+                    }
 #else
                     if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_pf, rs_pfb);
 #endif
@@ -535,69 +563,91 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             });
             wcur = wnext;
             sstage += (size_t)16 * HW;
-        }
+        };
+        chunk(0, std::true_type{});
+        for (int c = 1; c < nch; ++c) chunk(c, std::false_type{});
 
         W4_SEG(1);
-        // ---- output transform + epilogue: column half (6 -> 4) in registers, row half through LDS, 32 channels per pass ----
+        // ---- output transform + epilogue, one m-tile (16 channels) per pass.  Writer half (every wave, its frequency row
+        // i): the m-tile's 48 accumulators are read FOUR CHANNELS AT A TIME (the registers of an accumulator tile), the
+        // column transform A4 (6 -> 4) runs as packed fp32 on those channel vectors and each of the four results goes to LDS
+        // as one 16-byte piece.  Reader half: a thread owns a 2x4 tile of two channels, adds the four waves' values (A2),
+        // and finishes (bias, residual / GELU / GELU', stores).  Two exchange buffers: m-tile p + 1 is transformed and
+        // written between the issue of p's LDS reads and their use -- one barrier per pass.  The accumulators are not
+        // zeroed: the next item's first k-step runs with C = 0. ----
         if (!(W4_ABL & 8)) {
         // (the accumulators of m-tiles 0 / 1 were last written 36+ MFMAs ago; the nops cover the tail of the matrix pipe)
         asm volatile("s_nop 15\n\ts_nop 15");
         if constexpr (W4_PF_SLOT < 0) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_op, rs_bias);
-        w4_static_for<(MT + 1) / 2>([&](auto M0) __attribute__((always_inline)) {
-            constexpr int m0 = 2 * decltype(M0)::value;
-            constexpr int set = decltype(M0)::value & 1;
-            w4_static_for<16>([&](auto I) __attribute__((always_inline)) {
-                constexpr int hh = decltype(I)::value >> 3, h = (decltype(I)::value >> 2) & 1, r = decltype(I)::value & 3;
-                if constexpr (m0 + hh < MT) {
-                    // (M A4)[i][q]:  A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-                    constexpr int R0 = ((h * MT + m0 + hh) * W3_NF) * 4 + r;
-                    const float m_0 = w4_acc_read<R0>(), m_1 = w4_acc_read<R0 + 4>(), m_2 = w4_acc_read<R0 + 8>();
-                    const float m_3 = w4_acc_read<R0 + 12>(), m_4 = w4_acc_read<R0 + 16>(), m_5 = w4_acc_read<R0 + 20>();
-                    // ... and the registers are ready for the next item
-                    w4_acc_zero<R0>(); w4_acc_zero<R0 + 4>(); w4_acc_zero<R0 + 8>();
-                    w4_acc_zero<R0 + 12>(); w4_acc_zero<R0 + 16>(); w4_acc_zero<R0 + 20>();
-                    const float s12 = m_1 + m_2, d12 = m_1 - m_2, s34 = m_3 + m_4, d34 = m_3 - m_4;
-                    f32x4 t{m_0 + s12 + s34, fmaf(2.f, d34, d12), fmaf(4.f, s34, s12), fmaf(8.f, d34, d12) + m_5};
-                    *reinterpret_cast<f32x4*>(sX + ((wi * 32 + hh * 16 + kq * 4 + r) * 32 + h * 16 + l16) * 4) = t;
-                }
+        auto colxf = [&](auto M0) __attribute__((always_inline)) {
+            constexpr int m0 = decltype(M0)::value;
+            w4_static_for<2>([&](auto H) __attribute__((always_inline)) {
+                constexpr int h = decltype(H)::value;
+                constexpr int R0 = ((h * MT + m0) * W3_NF) * 4;
+                f32x4 m_[6];
+                w4_static_for<6>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+                    m_[j] = f32x4{w4_acc_read<R0 + 4 * j>(), w4_acc_read<R0 + 4 * j + 1>(), w4_acc_read<R0 + 4 * j + 2>(),
+                                  w4_acc_read<R0 + 4 * j + 3>()};
+                });
+                // (M A4)[i][q]:  A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+                // (differences as a + n1 b with an opaque -1: a plain fsub of a vector is not selected as v_pk_add_f32)
+                const f32x4 s12 = m_[1] + m_[2], d12 = n4 * m_[2] + m_[1], s34 = m_[3] + m_[4], d34 = n4 * m_[4] + m_[3];
+                float* d = xwrite + (m0 & 1) * W4_XB + h * 16 * 16;
+                const f32x4 t0 = m_[0] + s12 + s34, t1 = 2.f * d34 + d12, t2 = 4.f * s34 + s12, t3 = 8.f * d34 + d12 + m_[5];
+                if (W4_ABL & 512) { asm volatile("" ::"v"(t0), "v"(t1), "v"(t2), "v"(t3)); return; }
+                *reinterpret_cast<f32x4*>(d) = t0;
+                *reinterpret_cast<f32x4*>(d + 512) = t1;
+                *reinterpret_cast<f32x4*>(d + 1024) = t2;
+                *reinterpret_cast<f32x4*>(d + 1536) = t3;
             });
+        };
+        colxf(std::integral_constant<int, 0>{});
+        w4_static_for<MT>([&](auto M0) __attribute__((always_inline)) {
+            constexpr int m0 = decltype(M0)::value;
+            constexpr int set = m0 % NS;
             W4_SEG(2 + 3 * m0);
-            // operands of the NEXT pass: a whole pass (~4 000 cycles) ahead of their use
-            if constexpr (m0 + 2 < MT) ep_fetch(std::integral_constant<int, set ^ 1>{}, m0 + 2, rs_op, rs_bias);
-            lds_barrier();
+            // operands of a LATER pass, W4_PF_AHEAD passes ahead of their use (into the set the previous pass has just used)
+            if constexpr (m0 + W4_PF_AHEAD < MT)
+                ep_fetch(std::integral_constant<int, (m0 + W4_PF_AHEAD) % NS>{}, m0 + W4_PF_AHEAD, rs_op, rs_bias);
+            lds_barrier();                          // m-tile m0 is in its buffer; the other buffer has been read
             W4_SEG(3 + 3 * m0);
-            f32x4 yv[4][2];
+            const float* xr = xread + (m0 & 1) * W4_XB;
+            f32x2 tt[4][4];                         // [i][column] x channel pair
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!ep_in_block(m0, k)) continue;
-                const int cl = cg + 8 * k;                         // channel of the pass (0..31)
-                f32x4 t[4];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f32x4*>(sX + ((i * 32 + cl) * 32 + tile) * 4);
-                yv[k][0] = t[0] + t[1] + t[2];                     // Y[pp] = sum_i A2^T[pp][i] t[i]
-                yv[k][1] = t[1] - t[2] - t[3];
-            }
-            lds_barrier();
+                for (int q = 0; q < 4; ++q)
+                    tt[i][q] = (W4_ABL & 1024) ? f32x2{n1.x * (i + q), n1.y} : *reinterpret_cast<const f32x2*>(xr + (i * 4 + q) * 512);
+            // (behind the reads in the LDS queue, and beside their latency: the next m-tile's writer half)
+            if constexpr (m0 + 1 < MT) colxf(std::integral_constant<int, m0 + 1>{});
             W4_SEG(4 + 3 * m0);
+            f32x2 y0[4], y1[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!ep_in_block(m0, k)) continue;
-                const int so = ep_soff(m0, k);
+            for (int q = 0; q < 4; ++q) {
+                // Y[pp] = sum_i A2^T[pp][i] t_i:  row 0 = t_0 + t_1 + t_2, row 1 = t_1 - t_2 - t_3
+                y0[q] = tt[0][q] + tt[1][q] + tt[2][q];
+                y1[q] = n1 * tt[3][q] + (n1 * tt[2][q] + tt[1][q]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int so = ep_soff(m0, r);
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
-                    f32x4 w_ = yv[k][pp];
-                    if (ACT != 2) w_ += bsv[set][k];
+                    f32x4 w_ = pp == 0 ? f32x4{y0[0][r], y0[1][r], y0[2][r], y0[3][r]}
+                                       : f32x4{y1[0][r], y1[1][r], y1[2][r], y1[3][r]};
+                    if (ACT != 2) w_ += bsv[set][r];
                     if (ACT == 1) {
-                        ep_store(rs_pre, pp, so, w_);              // pre-activation (the training forward saves it;
-                                                                   // empty descriptor when out_pre is null: dropped)
+                        ep_store(rs_pre, pp, so, w_);          // pre-activation (the training forward saves it;
+                                                               // empty descriptor when out_pre is null: dropped)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w_[e] = gelu_erf(w_[e]);
                     }
                     if (ACT == 2) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w_[e] *= gelu_erf_grad(opv[set][k][pp][e]);
+                        for (int e = 0; e < 4; ++e) w_[e] *= gelu_erf_grad(opv[set][r][pp][e]);
                     } else {
-                        w_ += opv[set][k][pp];
+                        w_ += opv[set][r][pp];
                     }
                     ep_store(rs_out, pp, so, w_);
                 }
@@ -654,12 +704,18 @@ inline int conv_wino4_launch(const ConvArgs& a_in, hipStream_t st) {
     if (wpx > ipx) wpx = ipx;
     const unsigned grid = (unsigned)(wpx * 8);
     constexpr size_t lds = W4_LDS_FLOATS * sizeof(float);
+    // Work items have one fixed length (chunks x 240 MFMAs + epilogue), so CUs that start together stay in lock step and
+    // all epilogues -- the only phase that touches HBM in earnest: 80 KB of stores + 80 KB of operands per item -- come in
+    // one burst per item time.  The workgroups start in W4_STAGGER phases spread over one item time (s_memtime ticks
+    // ~ shader cycles: ~8.8 k per chunk + ~11 k of epilogue); launches with few items per CU are not staggered.
+    const int per_wg = (ipx + wpx - 1) / wpx;
+    const int stagger = (W4_STAGGER > 0 && per_wg >= 4 * W4_STAGGER) ? (a.nch3 * 8800 + 11000) / W4_STAGGER : 0;
     // (more than 64 KB of dynamic LDS needs the per-function opt-in; idempotent, so no cached flag / global state)
 #define W4_GO(ACT, EDGE)                                                                                                \
     do {                                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<ACT, EDGE>),                         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv_wino4_kernel<ACT, EDGE>), dim3(grid), dim3(256), lds, st, a, ipx, wpx);                \
+        hipLaunchKernelGGL((conv_wino4_kernel<ACT, EDGE>), dim3(grid), dim3(256), lds, st, a, ipx, wpx, stagger);       \
     } while (0)
 #ifdef W4_FORCE_EDGE
     const int edge = a.W % 2 == 0 ? 1 : 2;       // (debug: the masked variants are valid for every width)
@@ -681,7 +737,7 @@ inline int conv_wino4_launch(const ConvArgs& a_in, hipStream_t st) {
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
         const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
-        prof.note(1, fl, fl * (24.0 / 72.0));                                      // F(2x4): 24 multiplies per 8 outputs
+        prof.note(1, fl, fl * (24.0 / 72.0), 4);                                      // F(2x4): 24 multiplies per 8 outputs
     }
     SINDDM_LAUNCH_CHECK();
     return 0;

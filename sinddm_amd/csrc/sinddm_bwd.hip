@@ -5,7 +5,7 @@
 // (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
 #include "conv_mfma.h"
 #include "conv_wino.h"
-#include "conv_wino5.h"
+#include "conv_wino4.h"
 #include "internal.h"
 #include "wgrad_wino.h"
 
@@ -1050,10 +1050,64 @@ static int conv3x3_wino(const float* zero, const float* in3, int cin3, const flo
     if (SINDDM_WINO_V3 && wf && mt == 5 &&
         (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count()) {
         c.w3 = wf;
-        if (SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return SINDDM_WINO_V5 ? conv_wino5_launch(c, st) : conv_wino4_launch(c, st);
+        if (SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return conv_wino4_launch(c, st);
         return conv_wino3_launch(c, st);
     }
     return conv_wino_launch(c, mt, st);
+}
+
+// Backward of ONE SinDDMConvBlock (autograd of reference SinDDM/models.py:69-80): dO = gradient of the block output (scratch,
+// overwritten), xin = the block input, saved tensors of block l from `tb`; weight / bias gradients are ADDED into `grads`,
+// the per-sample condition gradient goes to tb.dcond, the input gradient to `dst` (skipped when null).  dU / dH: scratch.
+static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float* params, const float* packed_bwd,
+                          const float* xin, float* dO, float* dU, float* dH, float* dst, float* grads, const TrainBufs& tb,
+                          int B, int H, int W, hipStream_t st) {
+    const BlockPlan& b = P.blk[l];
+    const float* zp = packed_bwd + k.zero;
+    int rc;
+    const int nchK = (b.cout + KC - 1) / KC;
+    // conv2 + residual projection weight grads
+    rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr);
+    if (rc) return rc;
+    if (b.res_w >= 0) {
+        rc = wgrad_launch(zp, dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
+        if (rc) return rc;
+    }
+    // dU = dgrad_conv2(dO) * GELU'(u)
+    if (wino_enabled() && b.cout % 4 == 0)        // (K of both data-gradient convs = cout; % 4: see conv_wino_launch)
+        rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], k.wdg2f[l] >= 0 ? packed_bwd + k.wdg2f[l] : nullptr, tb.u[l], 2,
+                          dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
+    else
+        rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU,
+                            b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
+    if (rc) return rc;
+    // conv1 weight grads, dH = dgrad_conv1(dU)
+    rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
+    if (rc) return rc;
+    if (wino_enabled() && k.wdg1[l] >= 0 && b.cout % 4 == 0)
+        rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], k.wdg1f[l] >= 0 ? packed_bwd + k.wdg1f[l] : nullptr, nullptr, 0,
+                          dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
+    else
+        rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH,
+                            b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
+    if (rc) return rc;
+    // depthwise weight/bias grads and the per-sample condition grads
+    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
+                       grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
+    SINDDM_LAUNCH_CHECK();
+    // data grad w.r.t. the block input: dw^T(dH) + residual path
+    if (dst) {
+        const float* radd = dO;                      // identity residual
+        if (b.res_w >= 0) {
+            rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, dO, b.cout, packed_bwd + k.dres[l], nchK, nullptr, 0, dU,
+                                b.cin, k.mt1[l], k.cb1[l], B, H, W, st);     // dU is free again
+            if (rc) return rc;
+            radd = dU;
+        }
+        rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 static int net_backward_impl(const NetPlan& P, const float* params, const float* packed_bwd, const float* x,
@@ -1070,56 +1124,15 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
                         P.half, k.mtf, k.cbf, B, H, W, st);
     if (rc) return rc;
     for (int l = 3; l >= 0; --l) {
-        const BlockPlan& b = P.blk[l];
         const float* xin = (l == 0) ? x : tb.o[l - 1];
         float* dO = tb.s[di];
         float* dU = tb.s[(di + 1) & 3];
         float* dH = tb.s[(di + 2) & 3];
         float* dX = tb.s[(di + 3) & 3];
-        const int nchK = (b.cout + KC - 1) / KC;
-        // conv2 + residual projection weight grads
-        rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr);
+        float* dst = (l == 0) ? grad_x : dX;
+        rc = block_backward(P, k, l, params, packed_bwd, xin, dO, dU, dH, (l > 0 || grad_x) ? dst : nullptr, grads, tb, B, H, W, st);
         if (rc) return rc;
-        if (b.res_w >= 0) {
-            rc = wgrad_launch(zp, dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
-            if (rc) return rc;
-        }
-        // dU = dgrad_conv2(dO) * GELU'(u)
-        if (wino_enabled() && b.cout % 4 == 0)        // (K of both data-gradient convs = cout; % 4: see conv_wino_launch)
-            rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], k.wdg2f[l] >= 0 ? packed_bwd + k.wdg2f[l] : nullptr, tb.u[l], 2,
-                              dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
-        else
-            rc = conv1x1_or_3x3(zp, dO, b.cout, packed_bwd + k.dg2[l], nchK, nullptr, 0, nullptr, 0, tb.u[l], 2, dU,
-                                b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
-        if (rc) return rc;
-        // conv1 weight grads, dH = dgrad_conv1(dU)
-        rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
-        if (rc) return rc;
-        if (wino_enabled() && k.wdg1[l] >= 0 && b.cout % 4 == 0)
-            rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], k.wdg1f[l] >= 0 ? packed_bwd + k.wdg1f[l] : nullptr, nullptr, 0,
-                              dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
-        else
-            rc = conv1x1_or_3x3(zp, dU, b.cout, packed_bwd + k.dg1[l], nchK, nullptr, 0, nullptr, 0, nullptr, 0, dH,
-                                b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
-        if (rc) return rc;
-        // depthwise weight/bias grads and the per-sample condition grads
-        hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
-                           grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
-        SINDDM_LAUNCH_CHECK();
-        // data grad w.r.t. the block input: dw^T(dH) + residual path
-        if (l > 0 || grad_x) {
-            const float* radd = dO;                      // identity residual
-            if (b.res_w >= 0) {
-                rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, dO, b.cout, packed_bwd + k.dres[l], nchK, nullptr, 0, dU,
-                                    b.cin, k.mt1[l], k.cb1[l], B, H, W, st);     // dU is free again
-                if (rc) return rc;
-                radd = dU;
-            }
-            float* dst = (l == 0) ? grad_x : dX;
-            rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st);
-            if (rc) return rc;
-            di = (di + 3) & 3;
-        }
+        if (l > 0 || grad_x) di = (di + 3) & 3;
     }
     // ---- conditioning path ----
     CondBwdArgs ca{};
@@ -1213,6 +1226,42 @@ int sinddm_adam_ema_step(float* p, const float* g, float* m, float* v, float* em
     hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)bx), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v,
                        ema, step_size, beta1, beta2, eps, bc2_sqrt, ema_decay, mode, (long long)n);
     SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sinddm_debug_conv_path(int dim, int B, int H, int W) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    const BlockPlan& b = p.blk[2];                      // the dim -> dim block
+    return conv3x3_path(b.cout, b.cout, b.coblks, B, H, W);
+}
+
+int sinddm_debug_block_train(const float* params, const float* packed, const float* packed_bwd, int dim, int l,
+                             const float* x, const float* cond_bias, const float* grad_y, float* y, float* grad_x,
+                             float* grad_params, float* dcond, int B, int H, int W, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (!params || !packed || !packed_bwd || !x || !cond_bias || !grad_y || !y || !grad_params || !dcond || !ws ||
+        l < 0 || l > 3 || B <= 0 || H <= 0 || W <= 0)
+        return SINDDM_E_BADARG;
+    NetPlan p = make_plan(dim);
+    if (!p.ok) return SINDDM_E_BADSHAPE;
+    TrainBufs tb;
+    if (carve_train(p, B, H, W, static_cast<char*>(ws), &tb) > ws_bytes) return SINDDM_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const BlockPlan& b = p.blk[l];
+    const size_t HW = (size_t)H * W;
+    int rc = block_forward(p, l, params, packed, x, cond_bias, b.cin, tb.h[l], tb.g[l], tb.o[l], tb.u[l], B, H, W, st);
+    if (rc) return rc;
+    if (hipMemcpyAsync(y, tb.o[l], B * b.cout * HW * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SINDDM_E_BADARG;
+    if (hipMemcpyAsync(tb.s[0], grad_y, B * b.cout * HW * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SINDDM_E_BADARG;
+    const BwdPack k = make_bwd_pack(p);
+    rc = block_backward(p, k, l, params, packed_bwd, x, tb.s[0], tb.s[1], tb.s[2], grad_x, grad_params, tb, B, H, W, st);
+    if (rc) return rc;
+    if (hipMemcpy2DAsync(dcond, b.cin * sizeof(float), tb.dcond + b.cond_off, p.cond_stride * sizeof(float),
+                         b.cin * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SINDDM_E_BADARG;
     return 0;
 }
 

@@ -2,7 +2,7 @@
 // 5x5, MFMA 3x3 convs, final 1x1, and the HBM-bound diffusion elementwise kernels.
 #include "conv_mfma.h"
 #include "conv_wino.h"
-#include "conv_wino5.h"
+#include "conv_wino4.h"
 #include "internal.h"
 
 namespace sinddm {
@@ -820,6 +820,90 @@ struct ChainStep {
     unsigned long long seed, stream_id;
 };
 
+int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W) {
+    if (!wino_enabled() || cout % 4 != 0) return 0;
+    const bool f24 = mt_for(cout) == 5 && cout % 80 == 0 && cin >= 16 && cin % 16 == 0;
+    const bool v3 = SINDDM_WINO_V3 && f24 &&
+                    (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
+    if (v3 && SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return 4;
+    return v3 ? 3 : 2;
+}
+
+// One SinDDMConvBlock forward (reference SinDDM/models.py:69-80): depthwise 5x5 + per-sample condition -> hbuf, 3x3 conv +
+// GELU -> gbuf (pre-activation -> upre when the training forward saves it), 3x3 conv + residual (1x1 projection or
+// identity of `cur`) -> obuf.  `cond` = the block's per-sample bias rows ([B][cond_stride]; stride 0: one row for the batch).
+int block_forward(const NetPlan& P, int l, const float* params, const float* packed, const float* cur, const float* cond,
+                  int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st) {
+    const BlockPlan& b = P.blk[l];
+    int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0,
+                           hbuf, B, b.cin, H, W, st);
+    if (rc) return rc;
+    const bool wino = wino_enabled();
+    ConvArgs c1{};
+    c1.in = hbuf; c1.bias = packed + b.pk_b1; c1.out = gbuf;
+    c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
+    c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
+    c1.out_pre = upre;
+    constexpr int c3 = SINDDM_CONV_C3;
+    // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
+    const bool v3 = SINDDM_WINO_V3 && wino &&
+                    (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
+    // ... and the ones with several 8x32 items per CU its one-wave-per-SIMD form (weights shared by two n-tiles)
+    const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
+    if (v3 && b.pk_w1f >= 0) {
+        c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
+        rc = v4 ? conv_wino4_launch(c1, st) : conv_wino3_launch(c1, st);
+    } else if (wino && b.pk_wc1 >= 0 && b.cin % 4 == 0) {
+        c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
+        rc = conv_wino_launch(c1, b.mt, st);
+    } else if (b.cin == 3 && c3) {
+        // C_in = 3: dedicated VALU kernel straight from the PyTorch-layout weights
+        const int nwg = ((H * W + 255) / 256) * B;
+        int split = 1;                                       // channel groups: aim at >= ~2048 workgroups
+        while (split < 8 && nwg * split < 2048 && b.cout % (split * 2) == 0) split *= 2;
+        hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B, split), dim3(256), 0, st, hbuf,
+                           params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split);
+        SINDDM_LAUNCH_CHECK();
+        rc = 0;
+    } else {
+        c1.w3 = packed + b.pk_c1; c1.nch3 = b.nch1;
+        rc = conv_launch(c1, b.mt, st);
+    }
+    if (rc) return rc;
+    ConvArgs c2{};
+    c2.in = gbuf; c2.out = obuf;
+    c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;
+    c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
+    if (wino && b.cout % 4 == 0) {       // (C_in of conv2 = cout; % 4: see conv_wino_launch)
+        // Winograd 3x3; a 1x1 residual projection runs first on the direct kernel and is added as `resid`
+        if (b.nchr > 0) {
+            ConvArgs r1{};
+            r1.in2 = cur; r1.Cin2 = b.cin; r1.w1 = packed + b.pk_res; r1.nch1 = b.nchr; r1.nch3 = 0;
+            r1.bias = packed + b.pk_b2; r1.out = obuf; r1.Cout = b.cout; r1.coblks = b.coblks;
+            r1.B = B; r1.H = H; r1.W = W; r1.zero = packed + P.pk_zero;
+            rc = conv1x1_launch(r1, b.mt, st);
+            if (rc) return rc;
+            c2.resid = obuf; c2.bias = nullptr;          // in place: each thread reads resid[o] before writing out[o]
+        } else {
+            c2.resid = cur; c2.bias = packed + b.pk_b2;
+        }
+        c2.nch1 = 0;
+        if (v3 && b.pk_w2f >= 0) {
+            c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
+            rc = v4 ? conv_wino4_launch(c2, st) : conv_wino3_launch(c2, st);
+        } else {
+            c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2;
+            rc = conv_wino_launch(c2, b.mt, st);
+        }
+    } else {
+        c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.nch3 = b.nch2;
+        if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
+        else { c2.resid = cur; c2.nch1 = 0; }
+        rc = conv_launch(c2, b.mt, st);
+    }
+    return rc;
+}
+
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
                      hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
@@ -865,72 +949,8 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         float* hbuf = tb ? tb->h[l] : fb.buf[sel[0]];
         float* gbuf = tb ? tb->g[l] : fb.buf[sel[1]];
         float* obuf = tb ? tb->o[l] : fb.buf[sel[2]];
-        int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, fb.cond + b.cond_off, cond_stride, nullptr, 0,
-                               hbuf, B, b.cin, H, W, st);
-        if (rc) return rc;
-        const bool wino = wino_enabled();
-        ConvArgs c1{};
-        c1.in = hbuf; c1.bias = packed + b.pk_b1; c1.out = gbuf;
-        c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
-        c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
-        c1.out_pre = tb ? tb->u[l] : nullptr;
-        constexpr int c3 = SINDDM_CONV_C3;
-        // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
-        const bool v3 = SINDDM_WINO_V3 && wino &&
-                        (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
-        // ... and the ones with several 8x32 items per CU its one-wave-per-SIMD form (weights shared by two n-tiles)
-        const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
-        if (v3 && b.pk_w1f >= 0) {
-            c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
-            rc = v4 ? (SINDDM_WINO_V5 ? conv_wino5_launch(c1, st) : conv_wino4_launch(c1, st)) : conv_wino3_launch(c1, st);
-        } else if (wino && b.pk_wc1 >= 0 && b.cin % 4 == 0) {
-            c1.w3 = packed + b.pk_wc1; c1.nch3 = b.nchw1;
-            rc = conv_wino_launch(c1, b.mt, st);
-        } else if (b.cin == 3 && c3) {
-            // C_in = 3: dedicated VALU kernel straight from the PyTorch-layout weights
-            const int nwg = ((H * W + 255) / 256) * B;
-            int split = 1;                                       // channel groups: aim at >= ~2048 workgroups
-            while (split < 8 && nwg * split < 2048 && b.cout % (split * 2) == 0) split *= 2;
-            hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B, split), dim3(256), 0, st, hbuf,
-                               params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split);
-            SINDDM_LAUNCH_CHECK();
-            rc = 0;
-        } else {
-            c1.w3 = packed + b.pk_c1; c1.nch3 = b.nch1;
-            rc = conv_launch(c1, b.mt, st);
-        }
-        if (rc) return rc;
-        ConvArgs c2{};
-        c2.in = gbuf; c2.out = obuf;
-        c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;
-        c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
-        if (wino && b.cout % 4 == 0) {       // (C_in of conv2 = cout; % 4: see conv_wino_launch)
-            // Winograd 3x3; a 1x1 residual projection runs first on the direct kernel and is added as `resid`
-            if (b.nchr > 0) {
-                ConvArgs r1{};
-                r1.in2 = cur; r1.Cin2 = b.cin; r1.w1 = packed + b.pk_res; r1.nch1 = b.nchr; r1.nch3 = 0;
-                r1.bias = packed + b.pk_b2; r1.out = obuf; r1.Cout = b.cout; r1.coblks = b.coblks;
-                r1.B = B; r1.H = H; r1.W = W; r1.zero = packed + P.pk_zero;
-                rc = conv1x1_launch(r1, b.mt, st);
-                if (rc) return rc;
-                c2.resid = obuf; c2.bias = nullptr;          // in place: each thread reads resid[o] before writing out[o]
-            } else {
-                c2.resid = cur; c2.bias = packed + b.pk_b2;
-            }
-            c2.nch1 = 0;
-            if (v3 && b.pk_w2f >= 0) {
-                c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
-                rc = v4 ? (SINDDM_WINO_V5 ? conv_wino5_launch(c2, st) : conv_wino4_launch(c2, st)) : conv_wino3_launch(c2, st);
-            } else {
-                c2.w3 = packed + b.pk_wc2; c2.nch3 = b.nchw2;
-                rc = conv_wino_launch(c2, b.mt, st);
-            }
-        } else {
-            c2.w3 = packed + b.pk_c2; c2.bias = packed + b.pk_b2; c2.nch3 = b.nch2;
-            if (b.nchr > 0) { c2.in2 = cur; c2.Cin2 = b.cin; c2.w1 = packed + b.pk_res; c2.nch1 = b.nchr; }
-            else { c2.resid = cur; c2.nch1 = 0; }
-            rc = conv_launch(c2, b.mt, st);
-        }
+        const int rc = block_forward(P, l, params, packed, cur, fb.cond + b.cond_off, cond_stride, hbuf, gbuf, obuf,
+                                     tb ? tb->u[l] : nullptr, B, H, W, st);
         if (rc) return rc;
         cur = obuf;
         curb = sel[2];
@@ -1141,11 +1161,6 @@ int sinddm_debug_w4_ks(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_ks), sizeof(unsigned long long) * n);
 }
 #endif
-#ifdef W5_TIMING
-int sinddm_debug_w5_seg(unsigned long long* host_dst, int n) {
-    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w5_seg), sizeof(unsigned long long) * n);
-}
-#endif
 #ifdef W2_TIMING
 int sinddm_debug_w2_timing(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_dbg), sizeof(unsigned long long) * n);
@@ -1182,7 +1197,7 @@ int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flop
     double ms = 0.0, fl = 0.0, ex = 0.0;
     int64_t n = 0;
     for (int i = 0; i < p.used; ++i) {
-        if (kind != 0 && p.kind[i] != kind) continue;
+        if (kind >= 10 ? (p.kind[i] != kind / 10 || p.gen[i] != kind % 10) : (kind != 0 && p.kind[i] != kind)) continue;
         hipError_t e = hipEventSynchronize(p.ev[2 * i + 1]);
         if (e != hipSuccess) return (int)e;
         float t = 0.f;

@@ -43,13 +43,20 @@ def local_batch(global_batch: int) -> int:
     return shard_sizes(global_batch, world_size())[rank()]
 
 
-def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
+def _skip(force: bool) -> bool:
+    """Collectives are identities on a single process -- unless `force` asks for the real call (one-rank process
+    group: the RCCL code path of the multi-GPU runs, executable on a 1-GPU box; tests/test_gpu_rccl.py)."""
+    return not is_dist() or (world_size() == 1 and not force)
+
+
+def gather_batch(local: torch.Tensor, global_batch: int, force: bool = False, pad_to: int = 0) -> torch.Tensor:
     """All-gather the per-rank sample shards along dim 0 (uneven shards are padded to the largest
-    shard for the collective and trimmed afterwards).  Identity on a single process."""
-    if not is_dist() or world_size() == 1:
+    shard for the collective and trimmed afterwards).  Identity on a single process.  `pad_to` (tests): pad the shards
+    to at least this many samples, as ranks with a smaller shard do."""
+    if _skip(force):
         return local
     sizes = shard_sizes(global_batch, world_size())
-    mx = max(sizes)
+    mx = max(max(sizes), int(pad_to))
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], dim=0)
@@ -70,10 +77,10 @@ def shard_offset(global_batch: int) -> int:
     return sum(shard_sizes(global_batch, world_size())[:rank()])
 
 
-def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
+def allreduce_sum_(t: torch.Tensor, force: bool = False) -> torch.Tensor:
     """In-place SUM all-reduce (identity on a single process).  With the gloo backend device tensors are
     staged through the host, so the 2-process tests can share one GPU; nccl (RCCL) reduces in place."""
-    if not is_dist() or world_size() == 1:
+    if _skip(force):
         return t
     if t.is_cuda and td.get_backend() == "gloo":
         h = t.detach().cpu()
@@ -84,18 +91,18 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def broadcast_int(v: int, src: int = 0) -> int:
+def broadcast_int(v: int, src: int = 0, force: bool = False) -> int:
     """Agree on a host integer (e.g. the seed of the scale-pick generator)."""
-    if not is_dist() or world_size() == 1:
+    if _skip(force):
         return int(v)
     obj = [int(v)]
     td.broadcast_object_list(obj, src=src)
     return int(obj[0])
 
 
-def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+def broadcast_(t: torch.Tensor, src: int = 0, force: bool = False) -> torch.Tensor:
     """In-place broadcast (identity on a single process); host-staged under gloo like allreduce_sum_."""
-    if not is_dist() or world_size() == 1:
+    if _skip(force):
         return t
     if t.is_cuda and td.get_backend() == "gloo":
         h = t.detach().cpu()

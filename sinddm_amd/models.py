@@ -391,6 +391,9 @@ class MultiScaleGaussianDiffusion(nn.Module):
         self._host_ver = None
         # optional noise hook for parity tests: fn(kind, shape, s, t, device) -> tensor
         self.noise_fn = None
+        # replay aid: when set to a list, every host-side draw ('init' / 'renoise', the tensor itself) and every fused
+        # run of reverse steps (('chain', s, seed, [t...]): the in-kernel draws are sinddm_normal_fill(seed, i)) is logged
+        self.draw_log = None
 
     # ---- host copies of the per-t tables (scalar kernel arguments; no device sync per step) ----
     _TABS = ('alphas_cumprod', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
@@ -409,7 +412,10 @@ class MultiScaleGaussianDiffusion(nn.Module):
     def _draw(self, kind: str, shape, s: int, t: int, device) -> torch.Tensor:
         if self.noise_fn is not None:
             return self.noise_fn(kind, tuple(shape), int(s), int(t), device).contiguous()
-        return torch.randn(tuple(shape), device=device)
+        z = torch.randn(tuple(shape), device=device)
+        if self.draw_log is not None:
+            self.draw_log.append((kind, int(s), int(t), z.clone()))
+        return z
 
     def step_coefs(self, t: int, s: int, clip_denoised: bool = True) -> _lib.StepCoefs:
         """Host scalars of one reverse step (everything `extract` gathers in models.py:306-352)."""
@@ -625,6 +631,8 @@ class MultiScaleGaussianDiffusion(nn.Module):
         # the step noise is keyed on a 62-bit seed drawn from torch's CPU generator: torch.manual_seed() reproduces a
         # sample, seeding only the CUDA generator (torch.cuda.manual_seed) does not
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+        if self.draw_log is not None:
+            self.draw_log.append(("chain", s, seed, list(t_seq)))
         in_alt = C.c_int(0)
         _lib.check(lib.sinddm_sample_chain(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
