@@ -72,19 +72,11 @@ __device__ unsigned long long g_w4_ks[8 * 256 * 4 * 64];
 #ifndef W4_STG_SLOT
 #define W4_STG_SLOT 24         // first of the four slots of k-steps 0 / 1 in which the raw-tile groups of the next chunk are requested
 #endif
-#ifndef W4_PF_BRANCH
-#define W4_PF_BRANCH 1       // 1: the request sits behind a uniform branch on `last chunk`; 0: every chunk issues it, all but
-#endif                       // the last through an empty descriptor (measured: 12 empty loads cost ~600 cycles per chunk)
 #ifndef W4_PF_KS
 #define W4_PF_KS 3            // k-step / slot of a chunk in which the epilogue's pass-0 operands are requested (slot -1: at the
 #define W4_PF_SLOT 58         // top of the epilogue instead).  Late in the LAST chunk: what is queued behind these loads
 #endif                        // (vector memory returns in order) is only needed after the epilogue
-#ifndef W4_PF_AHEAD
-#define W4_PF_AHEAD 1         // the epilogue's per-pass operands (residual / pre-activation, bias) are requested this many passes
-#endif                        // ahead of their use (register sets: W4_PF_AHEAD + 1); the first W4_PF_AHEAD passes inside the last chunk
-#ifndef W4_STAGGER
-#define W4_STAGGER 0          // > 0: the workgroups start in this many phases, spread over one work-item time -- with every CU in
-#endif                        // lock step all 256 epilogues hit HBM at the same moment (see the launch code)
+constexpr int W4_PF_AHEAD = 1;  // the epilogue's per-pass operands are requested one pass ahead (two: no gain, profiles/r04_w4_stagger_prefetch_ab.txt)
 #ifndef W4_XF_SLOT
 #define W4_XF_SLOT 40          // the slot of a k-step behind whose MFMA the input-transform burst of the next k-step sits
 #endif
@@ -134,7 +126,7 @@ struct Wino4Item {
 };
 
 template <int ACT, int EDGE>
-__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd, int stagger) {
+__global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
     constexpr int MT = W3_MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sX = smem + 2 * W4_BUF;
@@ -220,18 +212,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         // (a 16-byte group that starts inside the image may run past its right edge into the next row when W % 4 != 0)
         nvn = W - (it.x0 + 4 * tc_ - 1);
     };
-#ifndef W4_STG_SPREAD
-#define W4_STG_SPREAD 1       // 1: the eight raw-tile requests of a chunk W4_STG_GAP slots apart, each written to LDS W4_STG_DIST slots
-#define W4_STG_GAP 15          //    later (0: two batches of four back to back: +2-3 % per launch at C3 -- the bursts of
-#define W4_STG_DIST 60         //    HBM-latency loads hold up the weight refills queued behind them, vector memory returns in order)
-#endif
-    f32x4 stg[W4_STG_SPREAD ? 8 : 4];               // two batches of four 16-byte groups per chunk (spread: a ring)
+    // the eight raw-tile requests of a chunk go out W4_STG_GAP MFMA slots apart, each is written to LDS W4_STG_DIST slots
+    // later (two batches of four back to back: +2-3 % per launch at C3 -- bursts of HBM-latency loads hold up the weight
+    // refills queued behind them, vector memory returns in order)
+    constexpr int W4_STG_GAP = 15, W4_STG_DIST = 60;
+    f32x4 stg[8];                                   // the chunk's eight 16-byte groups in flight
     const unsigned HW4 = (unsigned)HW * 4u;
     auto plane_ptr = [&](int ib) { return p.in + ((size_t)ib * p.Cin + wi * 4) * HW; };
     __amdgpu_buffer_rsrc_t rs_st;
     auto stage_load = [&](int n) __attribute__((always_inline)) {                  // n = 2 g + s: group s of channel wi*4 + g
         if (W4_ABL & 1) return;
-        stg[W4_STG_SPREAD ? n : n & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
+        stg[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
     };
     // LDS writes of a staged group: four ds_write_b32 at (register + IMMEDIATE) -- left to the compiler they became
     // ds_write2_b32 pairs whose 8-bit offsets need a v_add_u32 per pair, i.e. lone VALU in the MFMA stream.  (The asm
@@ -248,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         constexpr int off = (n >> 1) * W4_PS * 4;
         static_assert(off + 12 < 65536, "ds_write_b32 immediate offset");
         const unsigned addr = swb[n & 1];                   // (locals: asm operands do not capture in a generic lambda)
-        const float val = stg[W4_STG_SPREAD ? n : n & 3][e];
+        const float val = stg[n][e];
         asm volatile("ds_write_b32 %0, %1 offset:%c2" ::"v"(addr), "v"(val), "n"(off + 4 * e) : "memory");
     };
 
@@ -319,11 +310,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     int l = 0;
     if (!decode(l, it)) return;
     w4_acc_declare();
-    if (W4_STAGGER > 0 && stagger > 0) {
-        // start phase of this workgroup: pairs of neighbours (the two 80-channel blocks of a tile) stay together
-        const unsigned long long t_go = __builtin_amdgcn_s_memtime() + (unsigned long long)((ls >> 1) % W4_STAGGER) * (unsigned)stagger;
-        while (__builtin_amdgcn_s_memtime() < t_go) __builtin_amdgcn_s_sleep(16);
-    }
     make_goff(it);
     nv = nvn;
     int wb_it = wbase(it.cb);
@@ -336,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     auto stage_store0 = [&](int n) {
         float* d = smem + (wi * 4 + (n >> 1)) * W4_PS + swo[n & 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = stg[W4_STG_SPREAD ? n : n & 3][e];
+        for (int e = 0; e < 4; ++e) d[e] = stg[n][e];
     };
     rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(plane_ptr(it.b)), 0, 4 * (int)HW4, 0x00020000);
 #pragma unroll
@@ -368,14 +354,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     const int cg = kqr * 4 + hf * 2;              // first of the thread's two channels inside the m-tile
     using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
     using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+    // outputs / epilogue operands of tensors far beyond the 256 MB of last-level cache are written / read once: non-temporal
+    // hint (C3, 8.6 GB per tensor: -0.6 % per launch, -1.4 % per step; C2, 0.47 GB: +2 % -- profiles/r04_w4_nontemporal_ab.txt)
+    const bool nt = __builtin_amdgcn_readfirstlane((size_t)p.B * p.Cout * HW > ((size_t)1 << 28)) != 0;
     // a 4-pixel output quad goes out in NP pieces: one 16-byte access, or at images with W % 4 != 0 two 8-byte / four
     // 4-byte ones with per-piece validity.  vo[pp][piece] = byte offset of (channel cg, row y + pp, pixel x + piece
     // start) inside the sample, or OOB (hardware drop / zero fill); the channel of a pass rides in the SCALAR offset.
-#ifdef W4_DBG_EPEDGE
-    constexpr int EE = EDGE == 0 ? 1 : EDGE;     // (debug: 8-byte epilogue pieces also where 16-byte ones are possible)
-#else
     constexpr int EE = EDGE;
-#endif
     constexpr int NP = EE == 0 ? 1 : (EE == 1 ? 2 : 4);
     auto ep_geo = [&](const Wino4Item& g, unsigned (&vo)[2][NP]) __attribute__((always_inline)) {
         const int y = g.y0 + 4 * hr + 2 * trr, x = g.x0 + 4 * tcr;
@@ -393,6 +378,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     ep_geo(it, vo);
     auto ep_load = [&](const __amdgpu_buffer_rsrc_t& r, int pp, int soff) __attribute__((always_inline)) -> f32x4 {
         if constexpr (EE == 0) {
+            if (nt) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[pp][0], soff, 2));
             return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[pp][0], soff, 0));
         } else if constexpr (EE == 1) {
             const u32x2 a0 = __builtin_amdgcn_raw_buffer_load_b64(r, (int)vo[pp][0], soff, 0);
@@ -414,7 +400,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             // the compiler's hazard recogniser assumes that cannot bite when the scalar offset is a register and lets
             // the next channel's v_pk_add overwrite them in the following cycle -- on gfx950 it does bite)
             const unsigned voff = vo[pp][0];
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(r), "s"(soff) : "memory");
+            if (nt) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(r), "s"(soff) : "memory");
+            else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(u), "v"(voff), "s"(r), "s"(soff) : "memory");
         } else if constexpr (EE == 1) {
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{u[0], u[1]}, r, (int)vo[pp][0], soff, 0);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{u[2], u[3]}, r, (int)vo[pp][1], soff, 0);
@@ -456,7 +443,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
         const __amdgpu_buffer_rsrc_t rs_pre = rsrc_of(ACT == 1 ? p.out_pre : nullptr);
         const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.zero), 0, 0u, 0x00020000);
         const int cb_ch = it.cb * (MT * 16);
         auto ep_soff = [&](int m0, int r) -> int { return (cb_ch + m0 * 16 + r) * (int)plane_b; };
         // operands of one pass (= m-tile m0) into register set SET: the bias of the thread's two channels and, per channel
@@ -488,7 +474,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             if (last) sstage = base_nx;
             const bool live = dval && dch * 16 + wi * 4 < p.Cin;
             rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sstage), 0, live && !(W4_ABL & 32) ? 4 * (int)HW4 : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_pf = last ? rs_op : rs_none, rs_pfb = last ? rs_bias : rs_none;
             w4_static_for<4>([&](auto KS) __attribute__((always_inline)) {
                 constexpr int ks = decltype(KS)::value;
                 if constexpr (ks == 3) {
@@ -528,7 +513,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     if constexpr (s == W4_XF_SLOT) xf_burst(raw[0], raw[1], v[(ks + 1) & 1], mk);
                     // raw-tile staging of the next chunk, four 16-byte groups per batch: loaded in k-step 0 / 1, written
                     // to LDS a k-step later
-#if W4_STG_SPREAD
                     {   // request n at chunk slot 2 + GAP n, its four LDS writes from chunk slot 2 + DIST + GAP n on
                         constexpr int G = ks * 60 + s;
                         constexpr int G0 = 2, G1 = 2 + W4_STG_DIST;
@@ -537,25 +521,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                         if constexpr (G >= G1 && G < G1 + W4_STG_GAP * 8 && (G - G1) % W4_STG_GAP < 4)
                             stage_store(std::integral_constant<int, (G - G1) / W4_STG_GAP * 4 + (G - G1) % W4_STG_GAP>{});
                     }
-#else
-                    if constexpr (ks == 0 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT);
-                    if constexpr (ks == 1 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4>{});
-                    if constexpr (ks == 1 && s >= W4_STG_SLOT && s < W4_STG_SLOT + 4) stage_load(s - W4_STG_SLOT + 4);
-                    if constexpr (ks == 2 && s >= 4 && s < 20) stage_store(std::integral_constant<int, s - 4 + 16>{});
-#endif
                     // pass-0 operands of the epilogue, requested late in the item's LAST chunk (W4_PF_KS, W4_PF_SLOT: ahead of
-                    // their use).  No branch: every chunk issues the twelve loads, all but the last one through an empty
-                    // descriptor (no memory traffic; the registers are dead until the epilogue)
-#if W4_PF_BRANCH
+                    // their use) behind a uniform branch (issued in every chunk through an empty descriptor, twelve such
+                    // loads cost ~600 cycles per chunk)
                     if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) {
                         if (last) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_op, rs_bias);
                     }
-                    if constexpr (W4_PF_AHEAD >= 2 && ks == W4_PF_KS && s == W4_PF_SLOT - 28 && !(W4_ABL & 8)) {
-                        if (last) ep_fetch(std::integral_constant<int, 1>{}, 1, rs_op, rs_bias);
-                    }
-#else
-                    if constexpr (ks == W4_PF_KS && s == W4_PF_SLOT && !(W4_ABL & 8)) ep_fetch(std::integral_constant<int, 0>{}, 0, rs_pf, rs_pfb);
-#endif
                     // weight refills: a group is free behind the MFMAs of its last slot
                     if constexpr (!(W4_ABL & 2) && h == 1 && ((pos & 3) == 3 || pos == 14 || pos == 30)) load_a(ks & 1, pos >> 2, w_pre[ks]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -704,24 +675,15 @@ inline int conv_wino4_launch(const ConvArgs& a_in, hipStream_t st) {
     if (wpx > ipx) wpx = ipx;
     const unsigned grid = (unsigned)(wpx * 8);
     constexpr size_t lds = W4_LDS_FLOATS * sizeof(float);
-    // Work items have one fixed length (chunks x 240 MFMAs + epilogue), so CUs that start together stay in lock step and
-    // all epilogues -- the only phase that touches HBM in earnest: 80 KB of stores + 80 KB of operands per item -- come in
-    // one burst per item time.  The workgroups start in W4_STAGGER phases spread over one item time (s_memtime ticks
-    // ~ shader cycles: ~8.8 k per chunk + ~11 k of epilogue); launches with few items per CU are not staggered.
-    const int per_wg = (ipx + wpx - 1) / wpx;
-    const int stagger = (W4_STAGGER > 0 && per_wg >= 4 * W4_STAGGER) ? (a.nch3 * 8800 + 11000) / W4_STAGGER : 0;
-    // (more than 64 KB of dynamic LDS needs the per-function opt-in; idempotent, so no cached flag / global state)
+    // (more than 64 KB of dynamic LDS needs the per-function opt-in: once per kernel and process, its result checked)
 #define W4_GO(ACT, EDGE)                                                                                                \
     do {                                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<ACT, EDGE>),                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv_wino4_kernel<ACT, EDGE>), dim3(grid), dim3(256), lds, st, a, ipx, wpx, stagger);       \
+        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<ACT, EDGE>), \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);    \
+        if (attr_rc != hipSuccess) return (int)attr_rc;                                                                 \
+        hipLaunchKernelGGL((conv_wino4_kernel<ACT, EDGE>), dim3(grid), dim3(256), lds, st, a, ipx, wpx);                \
     } while (0)
-#ifdef W4_FORCE_EDGE
-    const int edge = a.W % 2 == 0 ? 1 : 2;       // (debug: the masked variants are valid for every width)
-#else
     const int edge = a.W % 4 == 0 ? 0 : (a.W % 2 == 0 ? 1 : 2);
-#endif
     switch ((a.act & 0xff) * 3 + edge) {
         case 0: W4_GO(0, 0); break;
         case 1: W4_GO(0, 1); break;
