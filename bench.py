@@ -429,9 +429,41 @@ def cpu_leg(cfg, n_scales, B, H, W, s, total_t):
             xc = O.p_sample(sched, sd, xc, total_t - 2 - n_cpu, s, zc, xt)
             n_cpu += 1
         ct = time.perf_counter() - t0
-    return {"value": round(cb * n_cpu / ct, 3), "unit": "sample-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_cpu} finest-scale p_sample steps of batch {cb} at {H}x{W} "
-                      f"(oracle/sinddm_oracle.py, torch CPU fp32, {cores} threads)"}
+    rec = {"value": round(cb * n_cpu / ct, 3), "unit": "sample-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{n_cpu} finest-scale p_sample steps of batch {cb} at {H}x{W} "
+                     f"(oracle/sinddm_oracle.py, torch CPU fp32, {cores} threads)"}
+    # SURVEY 8(d)'s other CPU figures, bounded the same way: the C1 chain end to end (193 evaluations, batch 1) and
+    # finest-scale C2 steps at batch 1 and batch 16
+    from sinddm_amd.configs import CONFIGS
+    extra = {}
+    with torch.no_grad():
+        c1 = CONFIGS["C1"]
+        sz = [(h, w) for (w, h) in c1["sizes"]]
+        s1 = O.make_schedule(c1["T"], len(sz), c1["rescale_losses"], 1, train_full_t=True)
+
+        class Noise(dict):
+            def __missing__(self, k):
+                return torch.randn((1, 3) + sz[k[1]])
+
+        t0 = time.perf_counter()
+        O.sample_chain(s1, sd, sz, Noise(), 1)
+        dt1 = time.perf_counter() - t0
+        extra["c1_full_sample"] = {"imgs_per_sec": round(1.0 / dt1, 4), "seconds": round(dt1, 2),
+                                   "sample": "one full C1 sample (3 scales, T=100, 193 evaluations, batch 1)"}
+        c2 = CONFIGS["C2"]
+        s2 = O.make_schedule(c2["T"], len(c2["sizes"]), c2["rescale_losses"], 1, train_full_t=True)
+        w2, h2 = c2["sizes"][-1]
+        for b2, nst in ((1, 6), (16, 2)):
+            xa, xb, za = (torch.randn(b2, 3, h2, w2) for _ in range(3))
+            O.p_sample(s2, sd, xa, 100, len(c2["sizes"]) - 1, za, xb)
+            t0 = time.perf_counter()
+            for i in range(nst):
+                xa = O.p_sample(s2, sd, xa, 99 - i, len(c2["sizes"]) - 1, za, xb)
+            dt2 = (time.perf_counter() - t0) / nst
+            extra[f"c2_finest_batch{b2}"] = {"sample_steps_per_sec": round(b2 / dt2, 3), "ms_per_step": round(dt2 * 1e3, 1),
+                                             "sample": f"{nst} p_sample steps of batch {b2} at {h2}x{w2}"}
+    rec["other_configs"] = extra
+    return rec
 
 
 def main():

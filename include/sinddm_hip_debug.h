@@ -48,10 +48,12 @@ int sinddm_debug_block_train(const float* params, const float* packed, const flo
                              void* stream);
 
 /* Host-only (no device call): the workgroup -> (slab, pixel split) table wgrad_wino_kernel would be launched with for a
- * Cin -> Cout 3x3 weight gradient over `ntiles` 4x16-pixel tiles on `ncu` compute units.  wg_out (>= 512 entries) receives
- * slab << 16 | split per workgroup id, splits_out (>= 256) the number of pixel splits of each (co block, ci block) slab.
- * Returns the number of workgroups (> 0) or a negative SINDDM_E_* code.  For tests of the load balance. */
-int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int32_t* splits_out);
+ * Cin -> Cout 3x3 weight gradient over `ntiles` 4x16-pixel tiles on `ncu` compute units.  wg_out (wg_cap entries) receives
+ * slab << 16 | split per workgroup id, splits_out (splits_cap entries) the number of pixel splits of each (co block, ci
+ * block) slab.  Returns the number of workgroups (> 0) or a negative SINDDM_E_* code (BADARG when a buffer is too small,
+ * BADSHAPE when the launch table cannot describe the shape -- the library then uses its direct kernels).  For tests. */
+int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int wg_cap, int32_t* splits_out,
+                           int splits_cap);
 
 #ifdef __cplusplus
 }

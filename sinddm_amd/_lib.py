@@ -83,7 +83,7 @@ def load() -> C.CDLL:
                                  C.POINTER(C.c_double)]),
         "sinddm_prof_end3": (i, [i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_double), i]),
-        "sinddm_debug_wgrad_map": (i, [i, i, i64, i, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+        "sinddm_debug_wgrad_map": (i, [i, i, i64, i, C.POINTER(C.c_uint32), i, C.POINTER(C.c_int32), i]),
         "sinddm_debug_conv_path": (i, [i, i, i, i]),
         "sinddm_debug_block_train": (i, [p, p, p, i, i, p, p, p, p, p, p, p, i, i, i, p, sz, p]),
         "sinddm_train_workspace_bytes": (sz, [i, i, i, i]),

@@ -535,10 +535,12 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         // rows of 16-byte groups (W % 4 == 0): the variant with 16-byte DMA and ds_read_b64 operands
         const bool wide = SINDDM_WGRAD_WIDE && W % 4 == 0;
         const size_t lds = (size_t)WW_STAGES * (wide ? WX_BUF : WW_BUF) * sizeof(float);
-        // (more than 64 KB of dynamic LDS needs the per-function opt-in; idempotent)
-        (void)hipFuncSetAttribute(wide ? reinterpret_cast<const void*>(&wgrad_wino_wide_kernel)
-                                       : reinterpret_cast<const void*>(&wgrad_wino_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // (more than 64 KB of dynamic LDS needs the per-function opt-in: once per kernel and process, its result checked)
+        static const hipError_t attr_wide = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_wide_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WW_STAGES * WX_BUF * sizeof(float)));
+        static const hipError_t attr_dword = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WW_STAGES * WW_BUF * sizeof(float)));
+        if ((wide ? attr_wide : attr_dword) != hipSuccess) return (int)(wide ? attr_wide : attr_dword);
         ConvProfiler& prof = conv_profiler();
         const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
         if (rec) {
@@ -1265,7 +1267,8 @@ int sinddm_debug_block_train(const float* params, const float* packed, const flo
     return 0;
 }
 
-int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int32_t* splits_out) {
+int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t* wg_out, int wg_cap, int32_t* splits_out,
+                           int splits_cap) {
     if (Cin < 1 || Cout < WW_CO || Cout % WW_CO || ntiles < 1 || !wg_out || !splits_out) return SINDDM_E_BADARG;
     WwArgs w{};
     w.Cin = Cin; w.Cout = Cout;
@@ -1274,6 +1277,7 @@ int sinddm_debug_wgrad_map(int Cin, int Cout, int64_t ntiles, int ncu, uint32_t*
     w.ntiles = (int)(ntiles > 0x7fffffff ? 0x7fffffff : ntiles);
     const int n = ww_build_map(w, ncu);
     if (n <= 0) return SINDDM_E_BADSHAPE;
+    if (n > wg_cap || w.coblks * w.ciblks > splits_cap) return SINDDM_E_BADARG;     // caller's buffers are too small
     for (int i = 0; i < n; ++i) wg_out[i] = w.map.wg[i];
     for (int q = 0; q < w.coblks * w.ciblks; ++q) splits_out[q] = w.map.S[q];
     return n;

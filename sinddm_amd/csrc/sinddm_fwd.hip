@@ -598,6 +598,9 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restr
 // =====================================================================================
 // diffusion elementwise kernels (HBM-bound)
 // =====================================================================================
+// VEC = 4: 16-byte accesses (n % 4 == 0 keeps every sample's base 16-byte aligned), four quads per thread requested
+// before the first one is used; VEC = 1: any n.  The per-sample coefficients are three scalar loads per workgroup.
+template <int VEC>
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ xo,
                                                        const float* __restrict__ nz, float* __restrict__ out,
                                                        const float* __restrict__ tabA, const float* __restrict__ tabB,
@@ -608,10 +611,38 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
     const float ca = tabA[t], cb = tabB[t];
     const float g = (xo != nullptr) ? gam[t] : 0.0f;
     const size_t base = (size_t)b * n;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float v = x0[base + i];
-        if (xo) v = g * v + (1.0f - g) * xo[base + i];   // models.py:584-585
-        out[base + i] = ca * v + cb * nz[base + i];      // models.py:574-575
+    if constexpr (VEC == 4) {
+        constexpr int UN = 4;
+        const long long nq = n >> 2;
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x0 + base);
+        const f32x4* o4 = xo ? reinterpret_cast<const f32x4*>(xo + base) : nullptr;
+        const f32x4* z4 = reinterpret_cast<const f32x4*>(nz + base);
+        f32x4* y4 = reinterpret_cast<f32x4*>(out + base);
+        for (long long q0 = (long long)blockIdx.x * (256 * UN) + threadIdx.x; q0 < nq; q0 += (long long)gridDim.x * (256 * UN)) {
+            f32x4 v[UN], z[UN], o[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long q = q0 + u * 256;
+                const bool ok = q < nq;
+                v[u] = ok ? __builtin_nontemporal_load(x4 + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                z[u] = ok ? __builtin_nontemporal_load(z4 + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (o4) o[u] = ok ? __builtin_nontemporal_load(o4 + q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long q = q0 + u * 256;
+                if (q >= nq) continue;
+                f32x4 w = v[u];
+                if (o4) w = g * w + (1.0f - g) * o[u];       // models.py:584-585
+                y4[q] = ca * w + cb * z[u];                   // models.py:574-575
+            }
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            float v = x0[base + i];
+            if (xo) v = g * v + (1.0f - g) * xo[base + i];   // models.py:584-585
+            out[base + i] = ca * v + cb * nz[base + i];      // models.py:574-575
+        }
     }
 }
 
@@ -1039,11 +1070,21 @@ int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, fl
                     int64_t n, void* stream) {
     if (!x0 || !noise || !out || !tab_sqrt_ac || !tab_sqrt_1m_ac || B <= 0 || n <= 0) return SINDDM_E_BADARG;
     if (x_orig && !gamma_row) return SINDDM_E_BADARG;
-    long long bx = (n + 255) / 256;
-    if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(q_sample_kernel, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
-                       x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
-                       reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+    const bool al = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(x_orig)) & 15) == 0;
+    if (n % 4 == 0 && al) {
+        long long bx = (n / 4 + 1023) / 1024;
+        if (bx > 4096) bx = 4096;
+        hipLaunchKernelGGL(q_sample_kernel<4>, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+                           x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
+                           reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+    } else {
+        long long bx = (n + 255) / 256;
+        if (bx > 4096) bx = 4096;
+        hipLaunchKernelGGL(q_sample_kernel<1>, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+                           x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
+                           reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+    }
     SINDDM_LAUNCH_CHECK();
     return 0;
 }

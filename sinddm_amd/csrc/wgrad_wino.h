@@ -68,7 +68,8 @@ struct WwArgs {
     WwMap map;
 };
 
-// returns the number of workgroups, or 0 when the table cannot describe the launch (caller reports BADSHAPE)
+// returns the number of workgroups, or 0 when the table cannot describe the launch (more slabs than it holds: the caller
+// then takes the direct weight-gradient kernels -- a slower path, not an error)
 inline int ww_build_map(WwArgs& w, int ncu) {
     const int slabs = w.coblks * w.ciblks;
     if (slabs > WW_MAXSLAB || ncu < 1) return 0;

@@ -1,12 +1,12 @@
 """GPU parity of conv_wino4.h (the one-wave-per-SIMD F(2x4,3x3) kernel): every EDGE variant (W % 4 == 0 / == 2 / odd),
 tile heights cut by the bottom image edge (H % 8 in {0, 2, 5}), both 80-channel blocks, and the GELU' data-gradient
-variant, at launches that carry at least SINDDM_V4_MIN_ITEMS_PER_CU = 4 (8x32 tile, 80-channel block) items per CU --
-the condition under which the library picks this kernel (csrc/conv_wino4.h: conv_wino4_applies).
+variant, at launches for which the library picks this kernel -- asked of the library itself (sinddm_debug_conv_path:
+4 = conv_wino4, 3 = conv_wino3, 2 = F(2x2) kernels), not re-derived from its threshold.
 
 The forward is compared with the oracle on the first and the last sample (samples are independent; the batch only
 has to be large enough to select the kernel).  The backward of a big batch (conv_wino4 data gradients) is compared with
-the sum of the backward passes of its quarters (small launches: conv_wino3 / conv_wino2 -- different kernels, same
-mathematics) and one quarter with oracle autograd.          reference SinDDM/models.py:63,65 (the 3x3 convolutions)
+the sum of the backward passes of its eighths (small launches: conv_wino3 / conv_wino2 -- different kernels, same
+mathematics) and with oracle autograd.          reference SinDDM/models.py:63,65 (the 3x3 convolutions)
 """
 import pytest
 import torch
@@ -17,11 +17,12 @@ from sinddm_amd.synth import closed_form_state_dict, hash_randn
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-N_CU = 256
 
 
-def _items(B, H, W, coblks=1):
-    return B * ((W + 31) // 32) * ((H + 7) // 8) * coblks
+def _path(B, H, W):
+    """Kernel generation the dim -> dim 3x3 convolutions of a launch of this shape take (both forward and data gradient)."""
+    from sinddm_amd import _lib
+    return _lib.load().sinddm_debug_conv_path(160, B, H, W)
 
 
 def _net(dim=160):
@@ -37,7 +38,7 @@ def _net(dim=160):
                                     (96, 48, 64),       # exact tiles, many samples
                                     (6, 186, 250)])     # C2-sized, W % 4 = 2, last tile column 26 wide
 def test_forward_vs_oracle(B, H, W):
-    assert _items(B, H, W) >= 4 * N_CU                  # every Winograd launch of the net takes conv_wino4
+    assert _path(B, H, W) == 4                          # the 160-channel launches of the net take conv_wino4
     net = _net()
     sd = closed_form_state_dict(160)
     x = hash_randn((B, 3, H, W), 77 + W) * 0.9
@@ -54,11 +55,11 @@ def test_forward_vs_oracle(B, H, W):
     assert torch.isfinite(got).all()
 
 
-@pytest.mark.parametrize("B,H,W", [(24, 94, 126), (12, 133, 177), (24, 96, 128)])
-def test_backward_big_batch_equals_sum_of_quarters(B, H, W):
-    """dgrad 3x3 convs of the big batch run on conv_wino4 (ACT = 0 and the GELU' variant ACT = 2); its quarters stay
-    below the item threshold."""
-    assert _items(B, H, W) >= 4 * N_CU and _items(B // 4, H, W, 2) < 4 * N_CU
+@pytest.mark.parametrize("B,H,W", [(24, 94, 126), (16, 133, 177), (24, 96, 128)])
+def test_backward_big_batch_equals_sum_of_eighths(B, H, W):
+    """dgrad 3x3 convs of the big batch run on conv_wino4 (ACT = 0 and the GELU' variant ACT = 2, every EDGE variant);
+    its eighths are launches the library sends to conv_wino3 / conv_wino2 -- an independent implementation."""
+    assert _path(B, H, W) == 4 and _path(B // 8, H, W) in (2, 3)
     net = _net()
     net.bind_grads()
     x = hash_randn((B, 3, H, W), 5)
@@ -73,9 +74,9 @@ def test_backward_big_batch_equals_sum_of_quarters(B, H, W):
         return y.detach().cpu(), xd.grad.cpu(), net.flat_grads.clone().cpu()
 
     y_all, gx_all, gp_all = run(slice(0, B))
-    q = B // 4
+    q = B // 8
     gp_sum = torch.zeros_like(gp_all)
-    for k in range(4):
+    for k in range(8):
         y_q, gx_q, gp_q = run(slice(k * q, (k + 1) * q))
         assert rel_l2(y_all[k * q:(k + 1) * q], y_q) < 5e-6
         assert rel_l2(gx_all[k * q:(k + 1) * q], gx_q) < 5e-5
@@ -88,14 +89,15 @@ def test_backward_big_batch_equals_sum_of_quarters(B, H, W):
         off += n
         cond_path = ".mlp." in name or "time_mlp" in name or "time_reshape" in name or name.endswith("ds_conv.bias")
         # (the condition-path / depthwise-bias gradients are sums over every pixel with heavy cancellation -- e.g. the three
-        # entries of l1.time_reshape.bias are ~1e-9 -- so batch vs quarters differ there by summation order alone)
+        # entries of l1.time_reshape.bias are ~1e-9 -- so batch vs eighths differ there by summation order alone)
         assert rel_l2(a, b) < (2e-3 if cond_path else 3e-4), name
 
 
-def test_backward_vs_oracle_autograd_on_conv_wino4():
+@pytest.mark.parametrize("B,H,W", [(24, 94, 126), (12, 133, 177)])      # EDGE = 1 and the odd-width EDGE = 2 / ACT = 2 variants
+def test_backward_vs_oracle_autograd_on_conv_wino4(B, H, W):
     """One training-shaped batch on conv_wino4 against oracle autograd (input gradient of every sample is independent:
-    two samples bound the CPU time; the parameter gradients are covered by the quarters test above)."""
-    B, H, W = 24, 94, 126
+    two samples bound the CPU time; the parameter gradients are covered by the eighths test above)."""
+    assert _path(B, H, W) == 4
     net = _net()
     net.bind_grads()
     net.flat_grads.zero_()

@@ -18,7 +18,7 @@ def _map(cin, cout, ntiles, ncu):
     lib = _lib.load()
     wg = (C.c_uint32 * 512)()
     sp = (C.c_int32 * 256)()
-    n = lib.sinddm_debug_wgrad_map(cin, cout, ntiles, ncu, wg, sp)
+    n = lib.sinddm_debug_wgrad_map(cin, cout, ntiles, ncu, wg, 512, sp, 256)
     return n, list(wg[:max(n, 0)]), list(sp)
 
 
@@ -64,3 +64,11 @@ def test_small_launches_and_bad_arguments():
     assert _map(160, 100, 100, 256)[0] < 0      # Cout not a multiple of the 80-channel slab
     assert _map(48 * 70, 80, 100, 256)[0] > 0   # 70 slabs: one workgroup each at least
     assert _map(48 * 300, 80, 100, 256)[0] < 0  # more slabs than the table holds
+    # the caller's buffers are sized by the caller: too small is reported, never overrun
+    lib = _lib.load()
+    wg = (C.c_uint32 * 8)()
+    sp = (C.c_int32 * 256)()
+    assert lib.sinddm_debug_wgrad_map(160, 160, 32 * 47 * 16, 256, wg, 8, sp, 256) == -1
+    wg = (C.c_uint32 * 512)()
+    sp = (C.c_int32 * 2)()
+    assert lib.sinddm_debug_wgrad_map(160, 160, 32 * 47 * 16, 256, wg, 512, sp, 2) == -1
