@@ -88,7 +88,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             cmd = [_hipcc(), *cflags, "-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print("[sinddm_amd.build]", " ".join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL)))
+            procs.append((cmd, subprocess.Popen(cmd, stderr=None if verbose else subprocess.DEVNULL, start_new_session=True)))
             objs.append(obj)
         failed = None
         try:
@@ -100,7 +100,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
             # never leave a compiler writing into the temporary directory that is about to be deleted
             for _, pr in procs:
                 if pr.poll() is None:
-                    pr.kill()
+                    try:                     # (hipcc is a driver: its clang children live in the same process group)
+                        os.killpg(pr.pid, 9)
+                    except OSError:
+                        pr.kill()
                 pr.wait()
         if failed:
             raise subprocess.CalledProcessError(*failed)

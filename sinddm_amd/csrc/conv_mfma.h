@@ -41,6 +41,8 @@ struct ConvArgs {
     int coblks;
     int mtp;             // (Winograd kernel) m-tiles per PACKED output-channel block; 0 = same as the kernel's MT
     int act;             // 0 none, 1 GELU, 2 multiply by GELU'(aux)
+    int Wt;              // 0, or the TRUE image width when rows are padded to W (a multiple of 4) inside the library's own
+                         // workspace: columns Wt .. W-1 of every input row hold zeros and are written as zeros
 };
 
 // geometry for NT 16-pixel tiles per wave (4 waves along N, tile width 32)

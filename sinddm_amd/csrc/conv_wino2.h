@@ -496,6 +496,9 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
             const_cast<float*>(p.bias ? p.bias : p.zero), 0, p.bias ? (unsigned)(p.coblks * MT * 16) * 4u : 0u, 0x00020000);
         const bool pix_ok = (y < H) & (x < W);
         const bool okpp[2] = {pix_ok, bool(pix_ok & (y + 1 < H))};
+        // padded rows (ConvArgs::Wt): the pair's columns beyond the true width are written as zeros
+        const bool padded = p.Wt > 0 && p.Wt < W;
+        const f32x2 pm{x < p.Wt ? 1.f : 0.f, x + 1 < p.Wt ? 1.f : 0.f};
         const int cl_lim = p.Cout - it.cb * (MT * 16) - cg;        // channel (m0, k) of this lane exists iff 16 m0 + 8 k < cl_lim
         const unsigned pix_o = ((unsigned)(it.cb * (MT * 16) + cg) * (unsigned)HW + (unsigned)(y * W + x)) * 4u;
         // channel k of pass m0 exists in the item's block for every lane, or for none (cg < 8): known at compile time
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                 for (int pp = 0; pp < 2; ++pp) {
                     const unsigned o = off_of(m0, k, pp);
                     if (ACT == 1) st2(rs_pre, o, yv[k][pp]);       // (empty descriptor when out_pre is null: dropped)
-                    st2(rs_out, o, val[k][pp]);
+                    st2(rs_out, o, padded ? val[k][pp] * pm : val[k][pp]);
                 }
             }
             W2_SEG(5 + (m0 / 2) * 5);
@@ -704,7 +707,7 @@ inline int conv_wino2_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
     }
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
-        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        const double fl = 2.0 * a.B * a.H * (a.Wt > 0 ? a.Wt : a.W) * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
         prof.note(1, fl, fl * (16.0 / 36.0), 2);
     }
     SINDDM_LAUNCH_CHECK();

@@ -281,6 +281,10 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
         const bool okpp[2] = {pix_ok, bool(pix_ok & (y + 1 < H))};
         const int cl_lim = p.Cout - it.cb * (MT * 16) - cg;
         const unsigned pix_o = ((unsigned)(it.cb * (MT * 16) + cg) * (unsigned)HW + (unsigned)(y * W + x)) * 4u;
+        // padded rows (ConvArgs::Wt): the quad's columns beyond the true width are written as zeros
+        const bool padded = p.Wt > 0 && p.Wt < W;
+        const int nvq = p.Wt - x;
+        const f32x4 pm{nvq > 0 ? 1.f : 0.f, nvq > 1 ? 1.f : 0.f, nvq > 2 ? 1.f : 0.f, nvq > 3 ? 1.f : 0.f};
         auto in_block = [](int m0, int k) { return m0 * 16 + 16 * k + 16 <= MT * 16; };
         auto off_of = [&](int m0, int k, int pp) -> unsigned {
             const bool ok = okpp[pp] & (m0 * 16 + 16 * k < cl_lim);
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                 for (int pp = 0; pp < 2; ++pp) {
                     const unsigned o = off_of(m0, k, pp);
                     if (ACT == 1) st4(rs_pre, o, yv[k][pp]);       // (empty descriptor when out_pre is null: dropped)
-                    st4(rs_out, o, val[k][pp]);
+                    st4(rs_out, o, padded ? val[k][pp] * pm : val[k][pp]);
                 }
             }
         }
@@ -444,7 +448,7 @@ inline int conv_wino3_launch(const ConvArgs& a_in, hipStream_t st) {
 #undef W3_GO
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
-        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        const double fl = 2.0 * a.B * a.H * (a.Wt > 0 ? a.Wt : a.W) * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
         prof.note(1, fl, fl * (24.0 / 72.0), 3);                                      // F(2x4): 24 multiplies per 8 outputs
     }
     SINDDM_LAUNCH_CHECK();

@@ -376,6 +376,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     };
     unsigned vo[2][NP], vo_nx[2][NP];
     ep_geo(it, vo);
+    // padded rows (ConvArgs::Wt): the quad's columns beyond the true width are written as zeros
+    const bool padded = __builtin_amdgcn_readfirstlane(p.Wt > 0 && p.Wt < W) != 0;
+    auto pad_mask = [&](const Wino4Item& g) __attribute__((always_inline)) -> f32x4 {
+        const int nvq = p.Wt - (g.x0 + 4 * tcr);
+        return f32x4{nvq > 0 ? 1.f : 0.f, nvq > 1 ? 1.f : 0.f, nvq > 2 ? 1.f : 0.f, nvq > 3 ? 1.f : 0.f};
+    };
+    f32x4 pm = {1.f, 1.f, 1.f, 1.f};
+    if (padded) pm = pad_mask(it);
     auto ep_load = [&](const __amdgpu_buffer_rsrc_t& r, int pp, int soff) __attribute__((always_inline)) -> f32x4 {
         if constexpr (EE == 0) {
             if (nt) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[pp][0], soff, 2));
@@ -620,12 +628,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     } else {
                         w_ += opv[set][r][pp];
                     }
+                    if (padded) w_ *= pm;
                     ep_store(rs_out, pp, so, w_);
                 }
             }
         });
         // reader geometry of the next item (VALU here, where nothing is hidden anyway, instead of in its main loop)
         ep_geo(nx, vo_nx);
+        if (padded) pm = pad_mask(nx);
         W4_SEG(20);
         }
         if (!have_next) break;
@@ -698,7 +708,7 @@ inline int conv_wino4_launch(const ConvArgs& a_in, hipStream_t st) {
 #undef W4_GO
     if (rec) {
         (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
-        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        const double fl = 2.0 * a.B * a.H * (a.Wt > 0 ? a.Wt : a.W) * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
         prof.note(1, fl, fl * (24.0 / 72.0), 4);                                      // F(2x4): 24 multiplies per 8 outputs
     }
     SINDDM_LAUNCH_CHECK();

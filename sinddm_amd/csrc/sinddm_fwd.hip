@@ -320,13 +320,16 @@ constexpr int DW_NX = DW_NX_;   // x-tiles per workgroup: all their loads are in
 __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
                                                        int cond_stride, const float* __restrict__ addt, int flip,
-                                                       float* __restrict__ out, int C, int H, int W, int groupsX) {
+                                                       float* __restrict__ out, int C, int H, int W, int groupsX, int pi,
+                                                       int po) {
+    // pi / po: row pitch of the input / output planes (floats; = W for plain tensors).  po > W: the library's padded
+    // workspace layout -- columns W .. po-1 are written as zeros (the 3x3 convs that read them rely on it)
     __shared__ __attribute__((aligned(16))) float tile[DW_NX][DW_HR * DW_RS];
     const int c = blockIdx.y, b = blockIdx.z;
     const int ty = blockIdx.x / groupsX, gxi = blockIdx.x - ty * groupsX;
     const int y0 = ty * DW_TH, xg0 = gxi * (DW_NX * DW_TW);
-    const size_t plane = ((size_t)b * C + c) * H * W;
-    const float* src = x + plane;
+    const size_t plane = ((size_t)b * C + c) * H * po;
+    const float* src = x + ((size_t)b * C + c) * H * pi;
     // stage all DW_NX halo tiles: every load is issued before the first LDS write (the loads are independent; a rolled
     // loop would wait for each one in turn and make the kernel latency-bound).  16-byte groups: a halo row is 33 groups
     // of 4 floats (columns x0-2 .. x0+129), 660 groups per tile, 3 per thread; the loads are BUFFER loads on the plane
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     constexpr int DW_GR = DW_RS / 4;                       // groups per halo row (33)
     constexpr int DW_NG = DW_HR * DW_GR;                   // groups per tile (660)
     constexpr int DW_LD = (DW_NG + 255) / 256;             // per thread (3)
-    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, H * W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, H * pi * 4, 0x00020000);
     f32x4 stg[DW_NX][DW_LD];
 #pragma unroll
     for (int t = 0; t < DW_NX; ++t) {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
             const bool rowok = i < DW_NG && x0 < W && gy >= 0 && gy < H;
             // the leftmost group of an image (gx = -2) is loaded from column 0 and shifted by two elements
             const bool left = gx < 0;
-            const int off = rowok ? (gy * W + (left ? 0 : gx)) * 4 : 0x40000000;     // (out of range -> zero fill)
+            const int off = rowok ? (gy * pi + (left ? 0 : gx)) * 4 : 0x40000000;    // (out of range -> zero fill)
             const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0));
             f32x4 v = left ? f32x4{0.f, 0.f, q[0], q[1]} : q;
 #pragma unroll
@@ -394,13 +397,13 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int gx = x0 + lane + 64 * h;
-            if (gx < W) {
+            if (gx < po) {
 #pragma unroll
                 for (int r = 0; r < DW_RW; ++r) {
                     const int gy = y0 + wv * DW_RW + r;
                     if (gy < H) {
-                        const size_t oidx = plane + (size_t)gy * W + gx;
-                        out[oidx] = addt ? o[r][h] + addt[oidx] : o[r][h];
+                        const size_t oidx = plane + (size_t)gy * po + gx;
+                        out[oidx] = gx < W ? (addt ? o[r][h] + addt[oidx] : o[r][h]) : 0.0f;
                     }
                 }
             }
@@ -421,7 +424,8 @@ constexpr int DWR_ROWS = DWR_ROWS_;
 __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ cond,
                                                             int cond_stride, const float* __restrict__ addt, int flip,
-                                                            float* __restrict__ out, int C, int H, int W, int bandsX) {
+                                                            float* __restrict__ out, int C, int H, int W, int bandsX, int Wt) {
+    // Wt: true width when the rows are padded to W (input pads hold zeros, output pads are written as zeros); else = W
     const int c = blockIdx.y, b = blockIdx.z;
     const int by = blockIdx.x / bandsX, bx = blockIdx.x - by * bandsX;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -470,6 +474,10 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
             const size_t o = plane + (size_t)gy * W + x4;
             f32x4 v = acc[r];
             if (addt) v += *reinterpret_cast<const f32x4*>(addt + o);
+            if (x4 + 4 > Wt) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) v[cc] = x4 + cc < Wt ? v[cc] : 0.0f;
+            }
             *reinterpret_cast<f32x4*>(out + o) = v;
         }
     }
@@ -479,19 +487,22 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
 #define SINDDM_DW_ROWS 1
 #endif
 
+// pi / po: row pitch of the input / output planes (0 = W).  po > W: padded workspace rows, pads written as zeros.
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
-                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st) {
-    if (SINDDM_DW_ROWS && W % 4 == 0 && W >= 192) {            // (a lane owns 4 columns: narrow images leave most of a wave idle)
-        const int bandsX = (W + 255) / 256, bandsY = (H + 4 * DWR_ROWS - 1) / (4 * DWR_ROWS);
+                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi, int po) {
+    if (pi <= 0) pi = W;
+    if (po <= 0) po = W;
+    if (SINDDM_DW_ROWS && pi % 4 == 0 && po == pi && pi >= 192) {   // (a lane owns 4 columns: narrow images leave most of a wave idle)
+        const int bandsX = (pi + 255) / 256, bandsY = (H + 4 * DWR_ROWS - 1) / (4 * DWR_ROWS);
         hipLaunchKernelGGL(dwconv5_rows_kernel, dim3(bandsX * bandsY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                           addt, flip, out, C, H, W, bandsX);
+                           addt, flip, out, C, H, pi, bandsX, W);
         SINDDM_LAUNCH_CHECK();
         return 0;
     }
     const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
     const int groupsX = (tilesX + DW_NX - 1) / DW_NX;
     hipLaunchKernelGGL(dwconv5_kernel, dim3(groupsX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                       addt, flip, out, C, H, W, groupsX);
+                       addt, flip, out, C, H, W, groupsX, pi, po);
     SINDDM_LAUNCH_CHECK();
     return 0;
 }
@@ -507,7 +518,8 @@ int dwconv_launch(const float* x, const float* w, const float* bias, const float
 __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               float* __restrict__ out_pre, int H, int W, int Cout,
-                                                              int co_per_block) {
+                                                              int co_per_block, int Wt) {
+    // Wt: true width when the rows are padded to W (pads: zeros in, zeros out); else = W
     const int HW = H * W;
     const int b = blockIdx.y;
     // blockIdx.z owns output channels [co0, co1): small images split the channel walk over several workgroups (one
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
         const float acc = fmaf(v[26], wc[26], acc2.x + acc2.y);
         if (live) {
             if (dpre) dpre[(size_t)co * HW] = acc;
-            dst[(size_t)co * HW] = gelu_erf(acc);
+            dst[(size_t)co * HW] = x < Wt ? gelu_erf(acc) : 0.0f;
         }
     }
 }
@@ -557,6 +569,51 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
 // =====================================================================================
 // final 1x1 conv (half -> 3)                      reference SinDDM/models.py:130-132,151
 // =====================================================================================
+// Padded workspace rows (inference, W % 4 != 0): the library keeps its own activations with a row pitch Wp = W rounded up
+// to 4 floats, pad columns zero, so that every scale runs the aligned kernels (16-byte accesses, no edge masks in the
+// matrix loops).  The boundary tensors stay plain: the network input is copied into a padded 3-channel buffer ...
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                       int Wp, long long nrows) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;       // one padded quad per thread
+    const int qpr = Wp >> 2;
+    if (q >= nrows * qpr) return;
+    const long long row = q / qpr;
+    const int x = (int)(q - row * qpr) * 4;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = x + e < W ? in[row * W + x + e] : 0.0f;
+    *reinterpret_cast<f32x4*>(out + row * Wp + x) = v;
+}
+// ... and the final 1x1 conv reads padded rows and writes the plain (B, 3, H, W) result
+__global__ __launch_bounds__(256) void final_conv1x1_pitch_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  int C, int H, int W, int Wp) {
+    const int b = blockIdx.y;
+    const int qpr = Wp >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * qpr) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const size_t HWp = (size_t)H * Wp;
+    const float* src = a + (size_t)b * C * HWp + (size_t)y * Wp + x;
+    f32x4 o0{bias[0], bias[0], bias[0], bias[0]}, o1{bias[1], bias[1], bias[1], bias[1]}, o2{bias[2], bias[2], bias[2], bias[2]};
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)c * HWp);
+        o0 += w[c] * v;
+        o1 += w[C + c] * v;
+        o2 += w[2 * C + c] * v;
+    }
+    const size_t HW = (size_t)H * W;
+    float* dst = out + (size_t)b * 3 * HW + (size_t)y * W + x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (x + e < W) {
+            dst[e] = o0[e];
+            dst[HW + e] = o1[e];
+            dst[2 * HW + e] = o2[e];
+        }
+    }
+}
 __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ out,
                                                             int C, int HW) {
@@ -785,6 +842,53 @@ __global__ __launch_bounds__(256) void final_conv_reverse_step_kernel(const floa
 }
 
 // standalone N(0,1) fill from the same generator (tests; initial / re-noise draws of the sampler)
+// the same for padded workspace rows (pitch Wp, true width W): a thread owns a padded quad of a row; the boundary tensors
+// (x_t, x-tilde, x_{t-1}) are plain, so its up to four pixels sit at an unaligned flat index and their N(0,1) draws -- keyed
+// on the FLAT quad index like everywhere else -- come from up to two Philox calls
+__global__ __launch_bounds__(256) void final_conv_reverse_step_pitch_kernel(
+    const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ xt,
+    const float* __restrict__ xtil, float* __restrict__ out, sinddm_step_coefs k, int C, int H, int W, int Wp,
+    unsigned long long seed, unsigned long long step) {
+    const int b = blockIdx.y;
+    const int qpr = Wp >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= H * qpr) return;
+    const int y = q / qpr, x = (q - y * qpr) * 4;
+    const size_t HWp = (size_t)H * Wp;
+    const long long HW = (long long)H * W;
+    const float* src = a + (size_t)b * C * HWp + (size_t)y * Wp + x;
+    f32x4 e[3] = {{bias[0], bias[0], bias[0], bias[0]}, {bias[1], bias[1], bias[1], bias[1]}, {bias[2], bias[2], bias[2], bias[2]}};
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)c * HWp);
+        e[0] += w[c] * v;
+        e[1] += w[C + c] * v;
+        e[2] += w[2 * C + c] * v;
+    }
+    const int nv = W - x;                                   // valid pixels of the quad (>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long i0 = ((long long)b * 3 + c) * HW + (long long)y * W + x;
+        const int r0 = (int)(i0 & 3);
+        float za[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (k.sigma != 0.0f) {
+            philox_normal4(seed, step, (unsigned long long)(i0 >> 2), za);
+            if (r0 != 0) philox_normal4(seed, step, (unsigned long long)(i0 >> 2) + 1ull, zb);
+        }
+        const float z8[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nv) {
+                float z = z8[j];                                                   // z8[r0 + j], r0 in 0..3
+                z = r0 == 1 ? z8[j + 1] : z;
+                z = r0 == 2 ? z8[j + 2] : z;
+                z = r0 == 3 ? z8[j + 3] : z;
+                const float xb = k.mode != 0 ? xtil[i0 + j] : 0.f;
+                out[i0 + j] = reverse_step_mean(k, xt[i0 + j], e[c][j], xb, 1.f, 0.f, false) + k.sigma * z;
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void philox_normal_kernel(float* __restrict__ out, long long n, unsigned long long seed,
                                                             unsigned long long step) {
     const long long n4 = (n + 3) >> 2;
@@ -836,9 +940,17 @@ static size_t cond_region_bytes(const NetPlan& P, int B) {
     const int rows = B > CHAIN_COND_ROWS ? B : CHAIN_COND_ROWS;
     return align_up((size_t)rows * P.cond_stride * sizeof(float), 256);
 }
+#ifndef SINDDM_PITCH
+#define SINDDM_PITCH 1        // 1: inference keeps its activations with rows padded to a multiple of 4 floats (W % 4 != 0 scales)
+#endif
+// row pitch of the library's own activation buffers in inference: W rounded up to 4 floats
+static int fwd_pitch(int W) { return (SINDDM_PITCH && W % 4 != 0) ? (W + 3) / 4 * 4 : W; }
+static size_t fwd_xpad_bytes(int B, int H, int W) {        // padded copy of the network input (only when the pitch differs)
+    return fwd_pitch(W) != W ? align_up((size_t)B * CHANNELS * H * fwd_pitch(W) * sizeof(float), 256) : 0;
+}
 static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
-    const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
-    return cond_region_bytes(P, B) + 4 * act;
+    const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
+    return cond_region_bytes(P, B) + 4 * act + fwd_xpad_bytes(B, H, W);
 }
 
 // sampler-run extras of net_forward_impl: the step's conditioning row (already computed, shared by the batch) and the
@@ -863,17 +975,21 @@ int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W) {
 // One SinDDMConvBlock forward (reference SinDDM/models.py:69-80): depthwise 5x5 + per-sample condition -> hbuf, 3x3 conv +
 // GELU -> gbuf (pre-activation -> upre when the training forward saves it), 3x3 conv + residual (1x1 projection or
 // identity of `cur`) -> obuf.  `cond` = the block's per-sample bias rows ([B][cond_stride]; stride 0: one row for the batch).
+// Wt > 0: padded workspace rows -- every tensor here (cur included) has row pitch W (a multiple of 4) and true width Wt.
 int block_forward(const NetPlan& P, int l, const float* params, const float* packed, const float* cur, const float* cond,
-                  int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st) {
+                  int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st,
+                  int Wt) {
     const BlockPlan& b = P.blk[l];
-    int rc = dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0,
-                           hbuf, B, b.cin, H, W, st);
+    int rc = Wt > 0 ? dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
+                                    Wt, st, W, W)
+                    : dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
+                                    W, st);
     if (rc) return rc;
     const bool wino = wino_enabled();
     ConvArgs c1{};
     c1.in = hbuf; c1.bias = packed + b.pk_b1; c1.out = gbuf;
     c1.B = B; c1.H = H; c1.W = W; c1.Cin = b.cin; c1.Cout = b.cout; c1.nch1 = 0;
-    c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero;
+    c1.coblks = b.coblks; c1.act = 1; c1.zero = packed + P.pk_zero; c1.Wt = Wt;
     c1.out_pre = upre;
     constexpr int c3 = SINDDM_CONV_C3;
     // launches with enough work for every workgroup slot take the F(2x4) kernel (25 % fewer MFMAs)
@@ -893,7 +1009,7 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         int split = 1;                                       // channel groups: aim at >= ~2048 workgroups
         while (split < 8 && nwg * split < 2048 && b.cout % (split * 2) == 0) split *= 2;
         hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B, split), dim3(256), 0, st, hbuf,
-                           params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split);
+                           params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split, Wt > 0 ? Wt : W);
         SINDDM_LAUNCH_CHECK();
         rc = 0;
     } else {
@@ -904,7 +1020,7 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     ConvArgs c2{};
     c2.in = gbuf; c2.out = obuf;
     c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;
-    c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero;
+    c2.coblks = b.coblks; c2.act = 0; c2.zero = packed + P.pk_zero; c2.Wt = Wt;
     if (wino && b.cout % 4 == 0) {       // (C_in of conv2 = cout; % 4: see conv_wino_launch)
         // Winograd 3x3; a 1x1 residual projection runs first on the direct kernel and is added as `resid`
         if (b.nchr > 0) {
@@ -939,6 +1055,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
                      hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
     FwdBuffers fb{};
+    float* xpad = nullptr;
     if (tb) {
         fb.cond = tb->cond;
     } else {
@@ -946,9 +1063,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         char* base = static_cast<char*>(ws);
         fb.cond = reinterpret_cast<float*>(base);
         base += cond_region_bytes(P, B);
-        const size_t act = align_up((size_t)B * P.dim * H * W * sizeof(float), 256);
+        const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
         for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
+        xpad = reinterpret_cast<float*>(base + 4 * act);
     }
+    // padded rows: inference only (the training workspace keeps plain tensors: backward reads them with the plain kernels)
+    const int Wp = tb ? W : fwd_pitch(W);
+    const bool padded = Wp != W;
     int cond_stride = P.cond_stride;
     if (cs) { fb.cond = const_cast<float*>(cs->cond_row); cond_stride = 0; }
 
@@ -969,6 +1090,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
     }
 
     const float* cur = x;
+    if (padded) {
+        const long long nrows = (long long)B * CHANNELS * H;
+        const long long nq = nrows * (Wp / 4);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, x, xpad, H, W, Wp, nrows);
+        SINDDM_LAUNCH_CHECK();
+        cur = xpad;
+    }
     int freeb[4] = {0, 1, 2, 3};
     int curb = -1;
     for (int l = 0; l < 4; ++l) {
@@ -981,12 +1109,23 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         float* gbuf = tb ? tb->g[l] : fb.buf[sel[1]];
         float* obuf = tb ? tb->o[l] : fb.buf[sel[2]];
         const int rc = block_forward(P, l, params, packed, cur, fb.cond + b.cond_off, cond_stride, hbuf, gbuf, obuf,
-                                     tb ? tb->u[l] : nullptr, B, H, W, st);
+                                     tb ? tb->u[l] : nullptr, B, H, Wp, st, padded ? W : 0);
         if (rc) return rc;
         cur = obuf;
         curb = sel[2];
     }
     const int HW = H * W;
+    if (padded) {
+        const unsigned gx = (unsigned)((H * (Wp / 4) + 255) / 256);
+        if (cs && cs->x_next)
+            hipLaunchKernelGGL(final_conv_reverse_step_pitch_kernel, dim3(gx, B), dim3(256), 0, st, cur, params + P.fin_w,
+                               params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, H, W, Wp, cs->seed, cs->stream_id);
+        else
+            hipLaunchKernelGGL(final_conv1x1_pitch_kernel, dim3(gx, B), dim3(256), 0, st, cur, params + P.fin_w,
+                               params + P.fin_b, out, P.half, H, W, Wp);
+        SINDDM_LAUNCH_CHECK();
+        return 0;
+    }
     if (cs && cs->x_next && HW % 4 == 0) {
         hipLaunchKernelGGL(final_conv_reverse_step_kernel, dim3((HW / 4 + 255) / 256, B), dim3(256), 0, st, cur,
                            params + P.fin_w, params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, HW, cs->seed,
@@ -1125,7 +1264,7 @@ int sinddm_sample_chain(const float* params, const float* packed, float* x, floa
     if (bx > 8192) bx = 8192;
     if (ws_bytes < fwd_workspace_bytes(p, B, H, W)) return SINDDM_E_WORKSPACE;
     float* cond_tab = static_cast<float*>(ws);                 // the conditioning region: one row per step of a run
-    const bool fuse_tail = (H * W) % 4 == 0;
+    const bool fuse_tail = (H * W) % 4 == 0 || fwd_pitch(W) != W;     // (padded rows: their own fused tail kernel)
     float* cur = x;
     float* nxt = x_alt;
     for (int i0 = 0; i0 < n_steps;) {
