@@ -117,6 +117,15 @@ int sinddm_sample_chain(const float* params, const float* packed, float* x, floa
                         const float* x_tilde, const sinddm_step_coefs* coefs /*host*/, const int* t_list /*host*/,
                         int n_steps, float scale, uint64_t seed, uint64_t stream_id0, int dim, int B, int H, int W,
                         void* ws, size_t ws_bytes, void* stream, int* result_in_alt /*host*/);
+/* The same with a second, caller-owned stream: runs whose launches carry only a few work items per CU (coarse pyramid
+ * scales) are executed as TWO half-batches -- the chains of a batch are independent -- whose launches overlap on `stream`
+ * and `aux_stream` (ordered against each other with events inside the call; on return both streams' work is ordered
+ * before anything enqueued on `stream` afterwards).  Results are identical to sinddm_sample_chain: the noise is keyed on
+ * the element's index inside the whole batch.  aux_stream = NULL: plain sinddm_sample_chain. */
+int sinddm_sample_chain2(const float* params, const float* packed, float* x, float* x_alt, float* eps,
+                         const float* x_tilde, const sinddm_step_coefs* coefs /*host*/, const int* t_list /*host*/,
+                         int n_steps, float scale, uint64_t seed, uint64_t stream_id0, int dim, int B, int H, int W,
+                         void* ws, size_t ws_bytes, void* stream, void* aux_stream, int* result_in_alt /*host*/);
 
 /* out[i] ~ N(0,1) from the same counter-based generator (the sampler's initial / re-noise draws, models.py:467,518) */
 int sinddm_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "sinddm_debug_block_train",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
-    "sinddm_cond_embed", "sinddm_cond_stride", "sinddm_sample_chain", "sinddm_normal_fill",
+    "sinddm_cond_embed", "sinddm_cond_stride", "sinddm_sample_chain", "sinddm_sample_chain2", "sinddm_normal_fill",
 )
 
 
@@ -75,6 +75,8 @@ def load() -> C.CDLL:
         "sinddm_reverse_step_edit": (i, [p, p, p, p, p, C.POINTER(StepCoefs), p, p, i, i, i, p]),
         "sinddm_sample_chain": (i, [p, p, p, p, p, p, C.POINTER(StepCoefs), C.POINTER(C.c_int), i, f, C.c_uint64, C.c_uint64,
                                     i, i, i, i, p, sz, p, C.POINTER(C.c_int)]),
+        "sinddm_sample_chain2": (i, [p, p, p, p, p, p, C.POINTER(StepCoefs), C.POINTER(C.c_int), i, f, C.c_uint64, C.c_uint64,
+                                     i, i, i, i, p, sz, p, p, C.POINTER(C.c_int)]),
         "sinddm_normal_fill": (i, [p, i64, C.c_uint64, C.c_uint64, p]),
         "sinddm_upsample_bilinear": (i, [p, p, i, i, i, i, i, p]),
         "sinddm_prof_begin": (i, []),

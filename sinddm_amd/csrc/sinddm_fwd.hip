@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void final_conv_reverse_step_kernel(const floa
                                                                       const float* __restrict__ xt,
                                                                       const float* __restrict__ xtil, float* __restrict__ out,
                                                                       sinddm_step_coefs k, int C, int HW,
-                                                                      unsigned long long seed, unsigned long long step) {
+                                                                      unsigned long long seed, unsigned long long step, int b0) {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (p >= HW) return;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void final_conv_reverse_step_kernel(const floa
     for (int c = 0; c < 3; ++c) {
         const long long i0 = ((long long)b * 3 + c) * HW + p;
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k.sigma != 0.0f) philox_normal4(seed, step, (unsigned long long)(i0 >> 2), z);
+        if (k.sigma != 0.0f) philox_normal4(seed, step, (unsigned long long)((i0 + (long long)b0 * 3 * HW) >> 2), z);
         const f32x4 x = *reinterpret_cast<const f32x4*>(xt + i0);
         f32x4 xb{0.f, 0.f, 0.f, 0.f};
         if (k.mode != 0) xb = *reinterpret_cast<const f32x4*>(xtil + i0);
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void final_conv_reverse_step_kernel(const floa
 __global__ __launch_bounds__(256) void final_conv_reverse_step_pitch_kernel(
     const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ xt,
     const float* __restrict__ xtil, float* __restrict__ out, sinddm_step_coefs k, int C, int H, int W, int Wp,
-    unsigned long long seed, unsigned long long step) {
+    unsigned long long seed, unsigned long long step, int b0) {
     const int b = blockIdx.y;
     const int qpr = Wp >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -869,11 +869,12 @@ __global__ __launch_bounds__(256) void final_conv_reverse_step_pitch_kernel(
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const long long i0 = ((long long)b * 3 + c) * HW + (long long)y * W + x;
-        const int r0 = (int)(i0 & 3);
+        const long long ig = i0 + (long long)b0 * 3 * HW;          // flat index inside the whole batch: the noise key
+        const int r0 = (int)(ig & 3);
         float za[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
         if (k.sigma != 0.0f) {
-            philox_normal4(seed, step, (unsigned long long)(i0 >> 2), za);
-            if (r0 != 0) philox_normal4(seed, step, (unsigned long long)(i0 >> 2) + 1ull, zb);
+            philox_normal4(seed, step, (unsigned long long)(ig >> 2), za);
+            if (r0 != 0) philox_normal4(seed, step, (unsigned long long)(ig >> 2) + 1ull, zb);
         }
         const float z8[8] = {za[0], za[1], za[2], za[3], zb[0], zb[1], zb[2], zb[3]};
 #pragma unroll
@@ -948,9 +949,15 @@ static int fwd_pitch(int W) { return (SINDDM_PITCH && W % 4 != 0) ? (W + 3) / 4 
 static size_t fwd_xpad_bytes(int B, int H, int W) {        // padded copy of the network input (only when the pitch differs)
     return fwd_pitch(W) != W ? align_up((size_t)B * CHANNELS * H * fwd_pitch(W) * sizeof(float), 256) : 0;
 }
-static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
+// what one network evaluation of batch B carves from its workspace: conditioning rows, 4 activation buffers, padded input
+static size_t fwd_workspace_core(const NetPlan& P, int B, int H, int W) {
     const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
     return cond_region_bytes(P, B) + 4 * act + fwd_xpad_bytes(B, H, W);
+}
+// ... and what sinddm_workspace_bytes reports: room for a sampler run that splits the batch into two halves on two
+// streams (sinddm_sample_chain2): the shared conditioning table + two cores of half the batch
+static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
+    return fwd_workspace_core(P, B, H, W) + 2 * cond_region_bytes(P, 1) + 4096;
 }
 
 // sampler-run extras of net_forward_impl: the step's conditioning row (already computed, shared by the batch) and the
@@ -961,6 +968,7 @@ struct ChainStep {
     float* x_next;
     sinddm_step_coefs coefs;
     unsigned long long seed, stream_id;
+    int b0;            // index of this call's first sample inside the whole batch (the noise is keyed on the whole batch's flat index)
 };
 
 int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W) {
@@ -1059,7 +1067,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
     if (tb) {
         fb.cond = tb->cond;
     } else {
-        if (ws_bytes < fwd_workspace_bytes(P, B, H, W)) return SINDDM_E_WORKSPACE;
+        if (ws_bytes < fwd_workspace_core(P, B, H, W)) return SINDDM_E_WORKSPACE;
         char* base = static_cast<char*>(ws);
         fb.cond = reinterpret_cast<float*>(base);
         base += cond_region_bytes(P, B);
@@ -1119,7 +1127,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         const unsigned gx = (unsigned)((H * (Wp / 4) + 255) / 256);
         if (cs && cs->x_next)
             hipLaunchKernelGGL(final_conv_reverse_step_pitch_kernel, dim3(gx, B), dim3(256), 0, st, cur, params + P.fin_w,
-                               params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, H, W, Wp, cs->seed, cs->stream_id);
+                               params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, H, W, Wp, cs->seed, cs->stream_id, cs->b0);
         else
             hipLaunchKernelGGL(final_conv1x1_pitch_kernel, dim3(gx, B), dim3(256), 0, st, cur, params + P.fin_w,
                                params + P.fin_b, out, P.half, H, W, Wp);
@@ -1129,7 +1137,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
     if (cs && cs->x_next && HW % 4 == 0) {
         hipLaunchKernelGGL(final_conv_reverse_step_kernel, dim3((HW / 4 + 255) / 256, B), dim3(256), 0, st, cur,
                            params + P.fin_w, params + P.fin_b, x, cs->x_tilde, cs->x_next, cs->coefs, P.half, HW, cs->seed,
-                           cs->stream_id);
+                           cs->stream_id, cs->b0);
         SINDDM_LAUNCH_CHECK();
         return 0;
     }
@@ -1250,24 +1258,61 @@ int sinddm_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t stream_id,
     return 0;
 }
 
-int sinddm_sample_chain(const float* params, const float* packed, float* x, float* x_alt, float* eps, const float* x_tilde,
-                        const sinddm_step_coefs* coefs, const int* t_list, int n_steps, float scale, uint64_t seed,
-                        uint64_t stream_id0, int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream,
-                        int* result_in_alt) {
+// sampler runs whose dim -> dim conv launches carry between LO and HI (8x32 tile, 80-channel block) items per CU AND leave
+// at least 4 % of their last round of items empty are run as two half-batches on two streams (sinddm_sample_chain2).
+// Below LO a half-batch falls onto the one-m-tile kernels (C2 48x64 at batch 16: -3.5 %); launches that fill their rounds
+// gain nothing (C2 94x126: -2 %); C2 67x90 +10 %, C4 65x82 +11 %, 86x109 +5 %, 113x144 +4.5 % (profiles/NOTES_r04.md).
+#ifndef SINDDM_SPLIT_ITEMS_HI
+#define SINDDM_SPLIT_ITEMS_HI 16
+#endif
+#ifndef SINDDM_SPLIT_ITEMS_LO
+#define SINDDM_SPLIT_ITEMS_LO 3
+#endif
+
+int sinddm_sample_chain2(const float* params, const float* packed, float* x, float* x_alt, float* eps, const float* x_tilde,
+                         const sinddm_step_coefs* coefs, const int* t_list, int n_steps, float scale, uint64_t seed,
+                         uint64_t stream_id0, int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream,
+                         void* aux_stream, int* result_in_alt) {
     if (!params || !packed || !x || !x_alt || !eps || !coefs || !t_list || !ws || n_steps < 0 || B <= 0 || H <= 0 || W <= 0)
         return SINDDM_E_BADARG;
     NetPlan p = make_plan(dim);
     if (!p.ok) return SINDDM_E_BADSHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t sx = static_cast<hipStream_t>(aux_stream);
     const long long n = (long long)B * CHANNELS * H * W;
     long long bx = ((n + 3) / 4 + 255) / 256;
     if (bx > 8192) bx = 8192;
     if (ws_bytes < fwd_workspace_bytes(p, B, H, W)) return SINDDM_E_WORKSPACE;
     float* cond_tab = static_cast<float*>(ws);                 // the conditioning region: one row per step of a run
     const bool fuse_tail = (H * W) % 4 == 0 || fwd_pitch(W) != W;     // (padded rows: their own fused tail kernel)
+    // Coarse pyramid scales: a launch carries a handful of work items per CU (C2 48x64 at batch 16: 1.5), every kernel ends
+    // in a partly filled round and pays its fixed ramp / drain, and each step is a chain of 16 dependent launches.  The
+    // chains of the batch are independent, so with a second stream the batch runs as TWO half-batches whose launches
+    // overlap: the tail round of one fills with the other's items.  Same numbers either way (the noise is keyed on the
+    // whole batch's flat index: ChainStep::b0).
+    const long long items = (long long)B * ((fwd_pitch(W) + 31) / 32) * ((H + 7) / 8) * 2;
+    const long long ncu = wino2_cu_count();
+    const long long rounds = (items + ncu - 1) / ncu;
+    const bool split = sx != nullptr && sx != st && B >= 2 && fuse_tail && n_steps > 0 && items < SINDDM_SPLIT_ITEMS_HI * ncu &&
+                       items >= SINDDM_SPLIT_ITEMS_LO * ncu && (rounds * ncu - items) * 25 >= rounds * ncu;
+    const int Bh[2] = {split ? (B + 1) / 2 : B, split ? B - (B + 1) / 2 : 0};
+    char* wsh[2] = {static_cast<char*>(ws), nullptr};
+    size_t wsz[2] = {ws_bytes, 0};
+    hipEvent_t ev_go = nullptr, ev_done = nullptr;
+    if (split) {
+        wsh[0] = static_cast<char*>(ws) + cond_region_bytes(p, B);
+        wsz[0] = fwd_workspace_core(p, Bh[0], H, W);
+        wsh[1] = wsh[0] + wsz[0];
+        wsz[1] = fwd_workspace_core(p, Bh[1], H, W);
+        if (hipEventCreateWithFlags(&ev_go, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
+            return SINDDM_E_BADARG;
+    }
+    const size_t hoff = (size_t)Bh[0] * CHANNELS * H * W;      // the second half's offset into x / x_alt / eps / x_tilde
     float* cur = x;
     float* nxt = x_alt;
-    for (int i0 = 0; i0 < n_steps;) {
+    int rc = 0;
+    for (int i0 = 0; i0 < n_steps && rc == 0;) {
         // a run: up to CHAIN_COND_ROWS steps whose t is an arithmetic progression (the sampler's always is)
         int len = 1, dt = 0;
         if (i0 + 1 < n_steps) {
@@ -1286,25 +1331,51 @@ int sinddm_sample_chain(const float* params, const float* packed, float* x, floa
         }
         hipLaunchKernelGGL(cond_kernel, dim3(len), dim3(128), 0, st, ca);
         SINDDM_LAUNCH_CHECK();
-        for (int i = i0; i < i0 + len; ++i) {
-            if (coefs[i].mode != 0 && !x_tilde) return SINDDM_E_BADARG;
-            ChainStep cs{};
-            cs.cond_row = cond_tab + (size_t)(i - i0) * p.cond_stride;
-            cs.x_tilde = x_tilde; cs.x_next = fuse_tail ? nxt : nullptr; cs.coefs = coefs[i];
-            cs.seed = (unsigned long long)seed; cs.stream_id = (unsigned long long)(stream_id0 + (uint64_t)i);
-            int rc = net_forward_impl(p, params, packed, cur, nullptr, t_list[i], scale, eps, B, H, W, ws, ws_bytes, st, nullptr, &cs);
-            if (rc) return rc;
+        if (split) {                                           // the second stream starts behind the table (and behind
+            (void)hipEventRecord(ev_go, st);                   // everything the caller enqueued before this call)
+            (void)hipStreamWaitEvent(sx, ev_go, 0);
+        }
+        for (int i = i0; i < i0 + len && rc == 0; ++i) {
+            if (coefs[i].mode != 0 && !x_tilde) { rc = SINDDM_E_BADARG; break; }
+            for (int h = 0; h < (split ? 2 : 1) && rc == 0; ++h) {
+                const size_t o = h ? hoff : 0;
+                ChainStep cs{};
+                cs.cond_row = cond_tab + (size_t)(i - i0) * p.cond_stride;
+                cs.x_tilde = x_tilde ? x_tilde + o : nullptr; cs.x_next = fuse_tail ? nxt + o : nullptr; cs.coefs = coefs[i];
+                cs.seed = (unsigned long long)seed; cs.stream_id = (unsigned long long)(stream_id0 + (uint64_t)i);
+                cs.b0 = h ? Bh[0] : 0;
+                rc = net_forward_impl(p, params, packed, cur + o, nullptr, t_list[i], scale, eps + o, Bh[h], H, W, wsh[h], wsz[h],
+                                      h ? sx : st, nullptr, &cs);
+            }
+            if (rc) break;
             if (!fuse_tail) {
                 hipLaunchKernelGGL(reverse_step_rng_kernel, dim3((unsigned)bx), dim3(256), 0, st, cur, eps, x_tilde, nxt, coefs[i],
                                    n, (unsigned long long)seed, (unsigned long long)(stream_id0 + (uint64_t)i));
-                SINDDM_LAUNCH_CHECK();
+                if (hipGetLastError() != hipSuccess) { rc = SINDDM_E_BADARG; break; }
             }
             float* t_ = cur; cur = nxt; nxt = t_;
         }
+        if (split) {                                           // the caller's stream continues behind both halves (and the
+            (void)hipEventRecord(ev_done, sx);                 // next run's table is not written under the second half)
+            (void)hipStreamWaitEvent(st, ev_done, 0);
+        }
         i0 += len;
     }
+    if (split) {
+        (void)hipEventDestroy(ev_go);                          // (destruction is deferred until the recorded work is done)
+        (void)hipEventDestroy(ev_done);
+    }
+    if (rc) return rc;
     if (result_in_alt) *result_in_alt = (cur == x_alt) ? 1 : 0;
     return 0;
+}
+
+int sinddm_sample_chain(const float* params, const float* packed, float* x, float* x_alt, float* eps, const float* x_tilde,
+                        const sinddm_step_coefs* coefs, const int* t_list, int n_steps, float scale, uint64_t seed,
+                        uint64_t stream_id0, int dim, int B, int H, int W, void* ws, size_t ws_bytes, void* stream,
+                        int* result_in_alt) {
+    return sinddm_sample_chain2(params, packed, x, x_alt, eps, x_tilde, coefs, t_list, n_steps, scale, seed, stream_id0, dim, B,
+                                H, W, ws, ws_bytes, stream, nullptr, result_in_alt);
 }
 
 int sinddm_reverse_step_edit(const float* x_t, const float* eps, const float* x_tilde, const float* noise, float* out,

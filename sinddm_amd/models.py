@@ -81,6 +81,20 @@ def _workspace(device: torch.device, nbytes: int, tag: str = "fwd") -> torch.Ten
     return ws
 
 
+_AUX: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _aux_stream(device: torch.device) -> int:
+    """A second stream per device for sinddm_sample_chain2 (coarse scales run as two overlapping half-batches)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _AUX.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=idx)
+        _AUX[idx] = st
+    return st.cuda_stream
+
+
 class _Leaf(nn.Module):
     """Holds one (weight, bias) pair under the reference's key names."""
 
@@ -394,6 +408,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
         # replay aid: when set to a list, every host-side draw ('init' / 'renoise', the tensor itself) and every fused
         # run of reverse steps (('chain', s, seed, [t...]): the in-kernel draws are sinddm_normal_fill(seed, i)) is logged
         self.draw_log = None
+        self.two_streams = True       # coarse scales as two half-batches on two streams (sinddm_sample_chain2)
 
     # ---- host copies of the per-t tables (scalar kernel arguments; no device sync per step) ----
     _TABS = ('alphas_cumprod', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod',
@@ -634,10 +649,12 @@ class MultiScaleGaussianDiffusion(nn.Module):
         if self.draw_log is not None:
             self.draw_log.append(("chain", s, seed, list(t_seq)))
         in_alt = C.c_int(0)
-        _lib.check(lib.sinddm_sample_chain(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
-                                           _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
-                                           ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device), C.byref(in_alt)),
-                   "sinddm_sample_chain")
+        # (the second stream lets the library run coarse scales as two overlapping half-batches; same numbers either way)
+        _lib.check(lib.sinddm_sample_chain2(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
+                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
+                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device),
+                                            _aux_stream(x.device) if self.two_streams else None, C.byref(in_alt)),
+                   "sinddm_sample_chain2")
         return x_alt if in_alt.value else x
 
     def _eps(self, x, t_dev, t_host, s):

@@ -119,3 +119,40 @@ def test_public_api_takes_fused_path_and_matches_at_fine_scales():
     img = d.sample(batch_size=4, s=0)
     assert torch.isfinite(img).all() and float(img.abs().max()) < 5 and float(img.std()) > 1e-3
     assert not torch.equal(img[0], img[1])                                  # independent chains
+
+
+@pytest.mark.parametrize("cfg,s,B", [("C2", 1, 16), ("C2", 1, 13), ("C4", 1, 16), ("C2", 2, 6), ("C3", 1, 16)])
+def test_two_stream_half_batches_equal_single_stream(cfg, s, B):
+    """sinddm_sample_chain2 with a second stream runs coarse-scale runs as two half-batches whose launches overlap; the
+    noise is keyed on the element's index inside the WHOLE batch, so both runs consume the same draws and must agree to
+    rounding (not bit for bit: a half-batch launch may take another Winograd kernel than the full batch, like any launch
+    size does) -- even and odd batches, plain and padded rows, scale 0 with real noise and finer scales."""
+    from sinddm_amd import _lib
+    from sinddm_amd.models import _workspace
+    lib = _lib.load()
+    net, d = build_diffusion(cfg, dim=160, device=DEV)
+    H, W = d.image_sizes[s]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x0 = torch.randn(B, 3, H, W, device=DEV, generator=g)
+    xt = torch.randn(B, 3, H, W, device=DEV, generator=g) * 0.5
+    ts = [30, 29, 28, 1, 0]
+    n = len(ts)
+    tab = d._coef_table(s)
+    coefs = (_lib.StepCoefs * n)(*[tab[t] for t in ts])
+    tl = (C.c_int * n)(*ts)
+    ws = _workspace(DEV, lib.sinddm_workspace_bytes(160, B, H, W))
+    aux = torch.cuda.Stream(device=DEV)
+    outs = []
+    for a in (None, aux.cuda_stream):
+        xa, xb, eps = x0.clone(), torch.empty_like(x0), torch.empty_like(x0)
+        flag = C.c_int(0)
+        _lib.check(lib.sinddm_sample_chain2(_lib.ptr(net.flat_params), _lib.ptr(net.packed_weights()), _lib.ptr(xa), _lib.ptr(xb),
+                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), 4242, 0, 160, B, H, W,
+                                            ws.data_ptr(), ws.numel(), _lib.stream_ptr(DEV), a, C.byref(flag)),
+                   "sinddm_sample_chain2")
+        torch.cuda.synchronize()
+        outs.append((xb if flag.value else xa).clone())
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[1].cpu(), outs[0].cpu()) < 2e-5
+    # the second half's draws are the whole batch's: with another key the halves would differ at the noise level (~1)
+    assert max_abs(outs[1][B - 1:].cpu(), outs[0][B - 1:].cpu()) < 1e-3

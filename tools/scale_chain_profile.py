@@ -9,6 +9,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 s = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 net, d = build_diffusion(cfg, 160, dev)
+d.two_streams = os.environ.get('SINDDM_ONE_STREAM', '0') != '1'
 H, W = d.image_sizes[s]
 x = torch.randn(B, 3, H, W, device=dev)
 d.img_prev_upsample = torch.randn(B, 3, H, W, device=dev).clamp(-1, 1)
@@ -19,4 +20,4 @@ t0 = time.perf_counter()
 x = d._run_steps(x, s, ts)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / len(ts)
-print(f"{cfg} scale {s} {H}x{W} batch {B}: {dt * 1e3:.4f} ms/step wall, {B * H * W / dt / 1e6:.1f} Mpx-steps/s")
+print(f"{cfg} scale {s} {H}x{W} batch {B} ({'two streams' if d.two_streams else 'one stream'}): {dt * 1e3:.4f} ms/step wall, {B * H * W / dt / 1e6:.1f} Mpx-steps/s")
