@@ -655,9 +655,9 @@ __global__ __launch_bounds__(256) void final_conv1x1_kernel(const float* __restr
 // =====================================================================================
 // diffusion elementwise kernels (HBM-bound)
 // =====================================================================================
-// VEC = 4: 16-byte accesses (n % 4 == 0 keeps every sample's base 16-byte aligned), four quads per thread requested
-// before the first one is used; VEC = 1: any n.  The per-sample coefficients are three scalar loads per workgroup.
-template <int VEC>
+// VEC = 4: 16-byte accesses (n % 4 == 0 keeps every sample's base 16-byte aligned), UN quads per thread requested before
+// the first one is used (4 for big tensors, 1 when that would leave CUs without workgroups); VEC = 1: any n.  The per-sample coefficients are three scalar loads per workgroup.
+template <int VEC, int UN>
 __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ xo,
                                                        const float* __restrict__ nz, float* __restrict__ out,
                                                        const float* __restrict__ tabA, const float* __restrict__ tabB,
@@ -669,7 +669,6 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
     const float g = (xo != nullptr) ? gam[t] : 0.0f;
     const size_t base = (size_t)b * n;
     if constexpr (VEC == 4) {
-        constexpr int UN = 4;
         const long long nq = n >> 2;
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x0 + base);
         const f32x4* o4 = xo ? reinterpret_cast<const f32x4*>(xo + base) : nullptr;
@@ -1220,15 +1219,21 @@ int sinddm_q_sample(const float* x0, const float* x_orig, const float* noise, fl
     const bool al = ((reinterpret_cast<uintptr_t>(x0) | reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(x_orig)) & 15) == 0;
     if (n % 4 == 0 && al) {
-        long long bx = (n / 4 + 1023) / 1024;
+        const bool big = (long long)B * (n / 4) >= 4LL * 1024 * 2048;       // >= 8 workgroups of 1024 quads per CU
+        long long bx = big ? (n / 4 + 1023) / 1024 : (n / 4 + 255) / 256;
         if (bx > 4096) bx = 4096;
-        hipLaunchKernelGGL(q_sample_kernel<4>, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
-                           x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
-                           reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+        if (big)
+            hipLaunchKernelGGL((q_sample_kernel<4, 4>), dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+                               x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
+                               reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
+        else
+            hipLaunchKernelGGL((q_sample_kernel<4, 1>), dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+                               x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
+                               reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
     } else {
         long long bx = (n + 255) / 256;
         if (bx > 4096) bx = 4096;
-        hipLaunchKernelGGL(q_sample_kernel<1>, dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
+        hipLaunchKernelGGL((q_sample_kernel<1, 1>), dim3((unsigned)bx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0,
                            x_orig, noise, out, tab_sqrt_ac, tab_sqrt_1m_ac, gamma_row,
                            reinterpret_cast<const long long*>(t_dev), t_host, (long long)n);
     }
