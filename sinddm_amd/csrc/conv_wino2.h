@@ -591,8 +591,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino2_kernel(ConvArgs p, i
                     f32x2 w_ = yv[k][pp] + bs_v[k];
                     if (ACT == 1) {
                         yv[k][pp] = w_;                            // pre-activation (training forward saves it)
-                        w_[0] = gelu_erf(w_[0]);
-                        w_[1] = gelu_erf(w_[1]);
+                        w_ = gelu_erf2(w_);
                     } else if (ACT == 2) {
                         w_[0] *= gelu_erf_grad(ax_v[k][pp][0]);
                         w_[1] *= gelu_erf_grad(ax_v[k][pp][1]);

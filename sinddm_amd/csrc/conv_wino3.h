@@ -380,8 +380,7 @@ __global__ __launch_bounds__(W2_THREADS, 2) void conv_wino3_kernel(ConvArgs p, i
                     f32x4 w_ = yv[k][pp] + bs_v[k];
                     if (ACT == 1) {
                         yv[k][pp] = w_;                            // pre-activation (the training forward saves it)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w_[e] = gelu_erf(w_[e]);
+                        w_ = gelu_erf4(w_);
                     } else if (ACT == 2) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w_[e] *= gelu_erf_grad(ax_v[k][pp][e]);

@@ -619,8 +619,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
                     if (ACT == 1) {
                         ep_store(rs_pre, pp, so, w_);          // pre-activation (the training forward saves it;
                                                                // empty descriptor when out_pre is null: dropped)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w_[e] = gelu_erf(w_[e]);
+                        w_ = gelu_erf4(w_);
                     }
                     if (ACT == 2) {
 #pragma unroll

@@ -549,8 +549,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
     f32x2 vp[13];
 #pragma unroll
     for (int j = 0; j < 13; ++j) vp[j] = f32x2{v[2 * j], v[2 * j + 1]};
-#pragma unroll 4
-    for (int co = co0; co < co1; ++co) {
+    auto dot27 = [&](int co) __attribute__((always_inline)) -> float {
         const float* wc = w + co * 27;          // wave-uniform -> scalar loads
         f32x2 acc2{bias[co], 0.f};
 #pragma unroll
@@ -558,7 +557,25 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
             const f32x2 wp{wc[2 * j], wc[2 * j + 1]};
             acc2 = __builtin_elementwise_fma(vp[j], wp, acc2);
         }
-        const float acc = fmaf(v[26], wc[26], acc2.x + acc2.y);
+        return fmaf(v[26], wc[26], acc2.x + acc2.y);
+    };
+    // (two output channels per iteration: their GELUs run as one packed sequence)
+    int co = co0;
+#pragma unroll 2
+    for (; co + 1 < co1; co += 2) {
+        const f32x2 acc{dot27(co), dot27(co + 1)};
+        if (live) {
+            if (dpre) {
+                dpre[(size_t)co * HW] = acc.x;
+                dpre[(size_t)(co + 1) * HW] = acc.y;
+            }
+            const f32x2 g = gelu_erf2(acc);
+            dst[(size_t)co * HW] = x < Wt ? g.x : 0.0f;
+            dst[(size_t)(co + 1) * HW] = x < Wt ? g.y : 0.0f;
+        }
+    }
+    if (co < co1) {
+        const float acc = dot27(co);
         if (live) {
             if (dpre) dpre[(size_t)co * HW] = acc;
             dst[(size_t)co * HW] = x < Wt ? gelu_erf(acc) : 0.0f;
