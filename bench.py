@@ -164,6 +164,86 @@ class Ctx:
         return sdist.gather_batch(cur.cpu(), self.world * B, force=True).to(self.dev)
 
 
+class _PowerSampler:
+    """Socket power and shader clock of the busiest GPU, sampled from the amdgpu hwmon files on a side thread while the
+    (untimed) roofline pass runs: whether the dominant kernel sits at the power limit is part of its roofline story --
+    at the limit the clock gives way (2.31 of 2.4 GHz at C3), and fewer cycles per item at the same energy per item buy
+    nothing.  Reported, never used in `value`.  Falls back to `rocm-smi`; every failure degrades to None."""
+
+    def __init__(self, period=0.05):
+        import glob
+        import threading
+        self.period, self.rows, self.stop = period, [], threading.Event()
+        self.hw = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+                   if os.path.exists(os.path.join(h, "power1_average")) or os.path.exists(os.path.join(h, "power1_input"))]
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _sample(self):
+        best = None
+        for h in self.hw:
+            w = self._read(os.path.join(h, "power1_average"))
+            if w is None:
+                w = self._read(os.path.join(h, "power1_input"))
+            if w is None:
+                continue
+            if best is None or w > best[0]:
+                best = (w, self._read(os.path.join(h, "freq1_input")), self._read(os.path.join(h, "power1_cap")))
+        if best is not None:
+            return best[0] * 1e-6, (best[1] * 1e-6 if best[1] else None), (best[2] * 1e-6 if best[2] else None)
+        try:
+            import re
+            import subprocess
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True,
+                                 text=True, timeout=5).stdout
+            w = [float(x) for x in re.findall(r"Package Power \(W\): ([0-9.]+)", out)]
+            cap = [float(x) for x in re.findall(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)]
+            clk = [float(x) for x in re.findall(r"sclk clock level: \S+ \((\d+)Mhz\)", out)]
+            cur = [x for x in w if not cap or x not in cap]
+            if cur:
+                i = max(range(len(cur)), key=lambda j: cur[j])
+                return cur[i], (clk[i] if i < len(clk) else None), (cap[0] if cap else None)
+        except Exception:
+            pass
+        return None
+
+    def _run(self):
+        while not self.stop.is_set():
+            r = self._sample()
+            if r is not None:
+                self.rows.append(r)
+            self.stop.wait(self.period)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join(timeout=10)
+
+    def summary(self):
+        if not self.rows:
+            return None
+        # (the first samples of a pass still show the idle clock: take the upper half by power)
+        rows = sorted(self.rows)[len(self.rows) // 2:]
+        w = [r[0] for r in rows]
+        f = [r[1] for r in rows if r[1]]
+        cap = next((r[2] for r in rows if r[2]), None)
+        return {"socket_w": round(sum(w) / len(w), 1), "socket_w_max": round(max(w), 1), "cap_w": cap,
+                "frac_of_cap": round(sum(w) / len(w) / cap, 3) if cap else None,
+                "sclk_mhz": round(sum(f) / len(f)) if f else None, "sclk_max_mhz": 2400, "samples": len(self.rows),
+                "source": "amdgpu hwmon (power1_average, freq1_input), upper half of the samples of the untimed roofline pass"
+                          if self.hw else "rocm-smi, sampled during the untimed roofline pass"}
+
+
 def _prof(lib, kind, reset):
     from sinddm_amd import _lib
     ms, n, fl, ex = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
@@ -212,8 +292,9 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     # steps with HIP events around every MFMA conv launch (on the launch stream)
     lib.sinddm_prof_begin()
     t0p = time.perf_counter()
-    img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
-    ctx.barrier()
+    with _PowerSampler() as power:
+        img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
+        ctx.barrier()
     dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     mix = {}
@@ -240,6 +321,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
                        f"({round(dt_prof / steps * 1e3, 4)} ms/step with the events on)",
         "achieved": round(executed, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+        "power": power.summary(),
         "traffic": traffic, "traffic_source": traffic_src,
         "hbm_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                      if traffic and avg_launch_ms > 0 else None),
