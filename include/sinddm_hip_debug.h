@@ -37,6 +37,12 @@ int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flop
  * implicit GEMM; negative = SINDDM_E_*.  Lets a test assert that it exercises the kernel it means to. */
 int sinddm_debug_conv_path(int dim, int B, int H, int W);
 
+/* Process-global switch of the experimental F(4x4,3x3) kernel (conv_wino6; 6 from sinddm_debug_conv_path): on != 0 lets the
+ * launches that qualify take it, 0 keeps them on conv_wino4.  Returns the previous value, or SINDDM_E_BADARG from a library
+ * built without the kernel (the default build: -DSINDDM_WINO_F44_BUILD=1 adds it).  For A/B measurements and parity tests of
+ * both kernels in one process. */
+int sinddm_debug_set_f44(int on);
+
 /* ONE SinDDMConvBlock (l = 0..3 of the plan of SinDDMNet(dim); reference SinDDM/models.py:51-80) forward + backward on
  * its own: x (B, C_in, H, W), cond_bias (B, C_in) = the block's per-sample condition (time_reshape(mlp(cond)),
  * models.py:74-76), grad_y (B, C_out, H, W).  Writes y, grad_x (may be NULL), dcond (B, C_in) = gradient of cond_bias, and

@@ -9,7 +9,7 @@ struct PackSeg {
     long long count;   // elements in this segment
     long long w;       // source weight offset (conv: [cout][cin][taps]), or bias offset
     long long w2;      // second bias offset to add (-1 none)
-    int kind;          // 0: conv chunks, 1: bias, 2: zero page, 3: Winograd F(2x2) 3x3 weights, 4: Winograd F(2x4) 3x3 weights
+    int kind;          // 0: conv chunks, 1: bias, 2: zero page, 3: Winograd F(2x2) 3x3 weights, 4: Winograd F(2x4) 3x3 weights, 5: Winograd F(4x4) 3x3 weights
     int cin, cout, taps, nch, mt, co_lds;
     int transpose;     // 1: data-gradient image (M = cin of the forward conv, taps flipped)
 };

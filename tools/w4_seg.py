@@ -15,6 +15,8 @@ try:
     from sinddm_amd import _lib
     from sinddm_amd.configs import build_diffusion
     lib = _lib.load()
+    if len(sys.argv) > 2 and sys.argv[2] == "f44":
+        lib.sinddm_debug_set_f44(1)
     dev = torch.device("cuda:0")
     net, d = build_diffusion("C3", 160, dev)
     x = torch.randn(8, 3, 411, 512, device=dev)
