@@ -50,7 +50,7 @@ __device__ __forceinline__ void w4_static_for(F&& f) {
 
 // Compile-time timing ablations (-DW4_ABL=bits; results are WRONG, never ship):
 //   1 no raw-tile staging   2 weights loaded once   4 no raw-patch LDS reads   8 no epilogue   16 no input transform
-//   256 epilogue without global loads / stores (2048: without the loads, 4096: without the stores)   512 ... without its LDS writes   1024 ... without its LDS reads
+//   128 raw-tile requests of a chunk contiguous (tile-major what-if)   256 epilogue without global loads / stores (2048: without the loads, 4096: without the stores)   512 ... without its LDS writes   1024 ... without its LDS reads
 #ifndef W4_ABL
 #define W4_ABL 0
 #endif
@@ -220,8 +220,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
     const unsigned HW4 = (unsigned)HW * 4u;
     auto plane_ptr = [&](int ib) { return p.in + ((size_t)ib * p.Cin + wi * 4) * HW; };
     __amdgpu_buffer_rsrc_t rs_st;
+    int lin_soff = 0;
+    auto tile_lin = [&](const Wino4Item& g) { return (g.y0 / W4_TH) * p.tilesX + g.x0 / W4_TW; };
     auto stage_load = [&](int n) __attribute__((always_inline)) {                  // n = 2 g + s: group s of channel wi*4 + g
         if (W4_ABL & 1) return;
+        // (128: the chunk's eight requests of a wave read ONE contiguous 8 KB of the image -- what a tile-major activation
+        // layout would make of the ten 160-byte row segments x 4 planes; same bytes, same sharing between the two blocks)
+        if (W4_ABL & 128) stg[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, lane * 16 + n * 1024, lin_soff, 0));
+        else
         stg[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_st, (W4_ABL & 64) ? lane * 16 : (int)goff[n & 1], (n >> 1) * (int)HW4, 0));
     };
     // LDS writes of a staged group: four ds_write_b32 at (register + IMMEDIATE) -- left to the compiler they became
@@ -482,6 +488,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino4_kernel(ConvArgs p, int item
             if (last) sstage = base_nx;
             const bool live = dval && dch * 16 + wi * 4 < p.Cin;
             rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sstage), 0, live && !(W4_ABL & 32) ? 4 * (int)HW4 : 0, 0x00020000);
+            if (W4_ABL & 128) {
+                rs_st = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(last ? base_nx : plane_ptr(it.b)), 0, live ? (1 << 26) : 0, 0x00020000);
+                lin_soff = ((last ? tile_lin(nx) : tile_lin(it)) * nch + dch) * 8192;
+            }
             w4_static_for<4>([&](auto KS) __attribute__((always_inline)) {
                 constexpr int ks = decltype(KS)::value;
                 if constexpr (ks == 3) {
