@@ -1,28 +1,35 @@
 // Winograd F(4x4, 3x3) 3x3 convolution on the gfx950 fp32 matrix cores: 36 multiplies per 16 outputs (2.25 per output)
 // instead of the 3.0 of F(2x4) -- a quarter of the MFMAs of conv_wino4.h gone.
 //
-// Why: the dominant kernel runs at the socket's power limit (profiles/NOTES_r04.md section 6: 1.34 kW of 1.4 kW at
-// 2.31 of 2.4 GHz).  Schedules that need fewer cycles at the same energy per item buy a lower clock; only less work buys
-// time, and three quarters of the energy of conv_wino4 are its MFMAs.
+// Why it was built: the dominant kernel runs at the socket's power limit (profiles/NOTES_r04.md section 6: 1.34 kW of 1.4 kW
+// at 2.31 of 2.4 GHz); schedules that need fewer cycles at the same energy per item buy a lower clock, so the hypothesis
+// was that only less matrix work buys time.
+//
+// STATUS (round 4): parity-green (tests/test_gpu_wino6.py, SQ_INSTS_MFMA = 0.75 x conv_wino4's) and NO FASTER than
+// conv_wino4 (C3 step 104.8 against 103.7 ms, profiles/r04e_f44_*.txt): the matrix pipe is not what bounds that kernel
+// (profiles/NOTES_r04.md section 9).  Experimental: compiled only with -DSINDDM_WINO_F44_BUILD=1, dispatched only behind
+// sinddm_debug_set_f44().  Its loads are asm the compiler does not track ("=v" outputs, AGPR destinations, LDS-DMA) with
+// the kernel's own vmcnt bookkeeping: correct in this build, but nothing stops a compiler from copying such a value
+// before the kernel's wait (the -DW4_TIMING / -DW4_KSTAMP builds of this file fault) -- pin the registers before shipping.
 //
 // Skeleton of conv_wino4.h (one persistent 4-wave workgroup per CU, a wave owns its SIMD and 512 registers, an item is
 // an 8x32-pixel tile x 80 output channels, raw halo tile 16 channels x 10 rows x 40 columns double-buffered in LDS,
-// accumulators in numbered AGPRs, A ring of two k-steps, the item's first k-step with C = 0), with the work split the
-// 6 x 6 frequency grid forces: 6 does not divide over 4 waves by rows, so WAVE (a, b), a, b in {0, 1}, owns the 3 x 3
-// BLOCK i in {3a .. 3a+2}, j in {3b .. 3b+2}: nine frequency GEMMs x five m-tiles x ONE n-tile of sixteen 4x4 output
-// tiles (2 x 8 tiles = the item's 8 x 32 pixels): 45 MFMAs per k-step (conv_wino4: 60), 180 accumulator registers,
-// every A fragment feeds one MFMA (256 B of L2 weight traffic per MFMA, 1.5x conv_wino4's bytes per k-step).
+// accumulators in numbered AGPRs, the item's first k-step with C = 0), with the work split the 6 x 6 frequency grid
+// forces: 6 does not divide over 4 waves by rows, so WAVE (a, b), a, b in {0, 1}, owns the 3 x 3 BLOCK
+// i in {3a .. 3a+2}, j in {3b .. 3b+2}: nine frequency GEMMs x five m-tiles x ONE n-tile of sixteen 4x4 output tiles
+// (2 x 8 tiles = the item's 8 x 32 pixels): 45 MFMAs per k-step (conv_wino4: 60), 180 accumulator registers, every A
+// fragment feeds one MFMA (256 B of L2 weight traffic per MFMA, 1.5x conv_wino4's bytes per k-step).
 //   * input transform per wave: rows 3a..3a+2 of B^T need patch rows a..a+4, columns 3b..3b+2 patch columns b..b+4 --
 //     25 of the 36 patch values; 6 operations per column for the row triple (packed over column pairs), 6 per row for the
 //     column triple: 36 VALU per k-step behind a wave-uniform branch on a / b.
+//   * A ring of FOUR k-steps (stage = k-step of the chunk; two stages in the 74 AGPRs the accumulators leave free).
 //   * output transform: writer half  T_ab[p][jj] = sum_{i in block} A^T[p][i] M[i][3b+jj]  (4 x 3 values per tile and
 //     channel) goes to LDS channel-minor ([wave][p][jj][tile][16 channels], 16-byte pieces, 48 KB per m-tile, two
 //     buffers); reader half: a thread owns rows 2 p' .. 2 p'+1 of a 4x4 tile for two channels, adds the two a-halves and
 //     applies A^T along the columns -- from there on the epilogue IS conv_wino4's (same thread -> pixel map: a thread
 //     finishes a 2x4 pixel block of two channels).
-//   * LDS: 64 KB raw tiles + 96 KB exchange = all 160 KB.  Raw-tile rows carry a 2-float skew per four rows
-//     (row R at R * 41 + 2 (R >> 2)): the 4x4 tile rows are 4 raw rows apart and 4 * 41 = 0 (mod 4) would put tile rows
-//     0 and 1 of a 32-lane group on the same banks.
+//   * LDS: 64 KB raw tiles + 96 KB exchange = all 160 KB.  Raw tiles arrive by 16-byte LDS-DMA (rows of eleven 16-byte
+//     groups, plane stride 448 floats): the 4-byte patch reads are 4-way bank-conflicted, which the LDS pipe absorbs.
 // Restrictions (the caller keeps conv_wino4 otherwise): W % 4 == 0 (EDGE 0 only), C_out % 80 == 0, C_in % 16 == 0,
 // C_in >= 32, the same items-per-CU rule.  Same ConvArgs / epilogue contract.  Numerics: tools/f44_model.py (the device's
 // operation order in numpy): 1.4e-6 rel-L2 per convolution at C_in = 160 (F(2x4): 6e-7).
