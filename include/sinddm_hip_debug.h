@@ -37,11 +37,21 @@ int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flop
  * implicit GEMM; negative = SINDDM_E_*.  Lets a test assert that it exercises the kernel it means to. */
 int sinddm_debug_conv_path(int dim, int B, int H, int W);
 
+/* The same question for INFERENCE launches (sinddm_net_forward / sinddm_sample_chain: rows padded to 4 floats inside the
+ * workspace): 7 = conv_h2 (binary16 hi/lo direct kernel, the default where a launch has >= 2 items of 8x64 pixels per CU),
+ * else the value sinddm_debug_conv_path gives for the padded shape. */
+int sinddm_debug_infer_path(int dim, int B, int H, int W);
+
 /* Process-global switch of the experimental F(4x4,3x3) kernel (conv_wino6; 6 from sinddm_debug_conv_path): on != 0 lets the
  * launches that qualify take it, 0 keeps them on conv_wino4.  Returns the previous value, or SINDDM_E_BADARG from a library
  * built without the kernel (the default build: -DSINDDM_WINO_F44_BUILD=1 adds it).  For A/B measurements and parity tests of
  * both kernels in one process. */
 int sinddm_debug_set_f44(int on);
+
+/* Process-global switch of the binary16 hi/lo direct 3x3 kernel (conv_h2.h; 7 from sinddm_debug_conv_path): 0 keeps the
+ * launches that qualify on the fp32-MFMA Winograd kernels, != 0 (the default) lets them take it.  Returns the previous value.
+ * For A/B measurements and parity tests of both paths in one process; the library itself never changes it. */
+int sinddm_debug_set_h2(int on);
 
 /* ONE SinDDMConvBlock (l = 0..3 of the plan of SinDDMNet(dim); reference SinDDM/models.py:51-80) forward + backward on
  * its own: x (B, C_in, H, W), cond_bias (B, C_in) = the block's per-sample condition (time_reshape(mlp(cond)),

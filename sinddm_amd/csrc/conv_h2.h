@@ -1,0 +1,417 @@
+// 3x3 convolution as a direct implicit GEMM on the gfx950 16-bit matrix pipe with fp32-equivalent products:
+// every fp32 operand is split into two binary16 pieces  a = a_hi + a_lo  (a_hi = rn16(a), a_lo = rn16(a - a_hi): 22
+// significand bits, |a - a_hi - a_lo| <= 2^-22 |a|) and the product a*b is the three MFMA terms
+//     a_hi*b_hi + a_hi*b_lo + a_lo*b_hi            (fp32 accumulate inside v_mfma_f32_32x32x16_f16),
+// the dropped a_lo*b_lo being <= 2^-22 |a b|.  Each binary16 x binary16 product is exact in fp32, so the only roundings
+// are the two splits and the accumulation -- the same class as an fp32 FMA chain (measured against float64 in
+// tests/test_gpu_h2.py, modelled in tools/h2_model.py) -- at 16/3 of the fp32 matrix rate.
+//
+// binary16 has 5 exponent bits, so both operands are brought to a known range by EXACT power-of-two scales that the
+// epilogue removes again:
+//   * weights: per output channel, 2^e with max|w| * 2^e in [2^13, 2^14), chosen when the weights are packed;
+//   * activations: per launch, from the running max |x| of the tensor (`amax_in`, a device scalar its producer kernel
+//     maintains with one guarded atomicMax per wave); scaled max in [2^13, 2^14).
+// Pieces that fall below the binary16 normal range lose at most 2^-25 absolute = 2^-38 of the tensor's max.
+//
+// GEMM view: rows = 32 consecutive pixels of an image row (A operand, from the activation tile in LDS), columns = 32
+// output channels (B operand, packed weights), K = 16 input channels of one tap.  A workgroup = 8 waves (two per SIMD)
+// owns an 8 x 64 pixel item for ALL output channels (NT column tiles; C_out = 80 is padded to 96): wave w = image row w,
+// two row tiles; 2 x NT x 16 accumulator registers.  K order: 16-channel chunk -> kernel row ty -> kernel column tx.
+// Per chunk the raw fp32 halo tile (10 x 66 pixels x 16 channels) is loaded to registers, scaled, split and written to
+// LDS as [piece][k half][row][col][8 x f16] (16-byte A fragments, conflict-free), double buffered; the weights of one
+// (chunk, ty) = 3 taps x 2 pieces x NT fragments arrive by LDS-DMA in fragment order, ring of two; one barrier per
+// (chunk, ty).  Persistent: one workgroup per CU walks its XCD's contiguous range of items.
+//
+// Replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] / nn.Conv2d(dim_out, dim_out, 3, padding=1) [+ residual] of
+// SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80).
+#pragma once
+#include "conv_mfma.h"
+#include "conv_wino2.h"
+
+namespace sinddm {
+
+using h16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int H2_TH = 8, H2_TW = 64, H2_RS = H2_TW + 2, H2_HR = H2_TH + 2;
+constexpr int H2_PLANE = H2_HR * H2_RS * 16;          // bytes of one (piece, k-half) plane: 10 560
+constexpr int H2_ACT = 4 * H2_PLANE;                  // one activation buffer: 42 240
+constexpr int H2_TASKS = 2 * H2_HR * H2_RS;           // (k half, row, col) staging tasks per chunk: 1 320
+constexpr int H2_IT = (H2_TASKS + 511) / 512;         // per thread: 3
+constexpr int H2_TARGET_EXP = 13;                     // scaled max in [2^13, 2^14)
+
+template <int NT>
+struct H2Cfg {
+    static constexpr int W_SLOT = 3 * 2 * NT * 1024;              // bytes of one (chunk, ty) weight slot
+    static constexpr int LDS = 2 * H2_ACT + 2 * W_SLOT;           // NT = 5: 145 920
+    static constexpr int W_INSTR = W_SLOT / 1024;                 // 1 KB wave-instructions per slot
+};
+
+// exact power of two 2^s as a float, s in [-126, 127]
+__host__ __device__ __forceinline__ float h2_pow2(int s) {
+    union { unsigned u; float f; } c;
+    c.u = (unsigned)(s + 127) << 23;
+    return c.f;
+}
+// shift s such that m * 2^s lies in [2^13, 2^14); 0 for m = 0 / non-finite
+__device__ __forceinline__ int h2_shift_for(float m) {
+    const unsigned bits = __float_as_uint(m) & 0x7fffffffu;
+    const int e = (int)(bits >> 23);
+    if (e == 0 || e == 255) return 0;
+    int s = H2_TARGET_EXP - (e - 127);
+    return s > 100 ? 100 : (s < -100 ? -100 : s);
+}
+
+// running max |x| of a tensor: one guarded atomic per wave (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void amax_publish(float m, float* slot) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(m);
+        unsigned* s = reinterpret_cast<unsigned*>(slot);
+        if (bits > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(s, bits);
+    }
+}
+
+// ---- weight packing --------------------------------------------------------------------------------------------
+// per output channel: 2^-e (what the epilogue multiplies by), e = shift of max |w| over (ci, tap) to [2^13, 2^14)
+__global__ __launch_bounds__(256) void h2_wscale_kernel(const float* __restrict__ w, float* __restrict__ wsinv, int cin,
+                                                         int cout, int transpose) {
+    // forward: output channel co of W[co][ci][tap]; data gradient: output channel = forward ci (W'[ci][co][flip tap])
+    const int m = blockIdx.x;
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    float mx = 0.f;
+    if (m < M)
+        for (int i = threadIdx.x; i < K * 9; i += 256) {
+            const int k = i / 9, tap = i - k * 9;
+            const float v = transpose ? w[((long long)k * cin + m) * 9 + tap] : w[((long long)m * cin + k) * 9 + tap];
+            mx = fmaxf(mx, fabsf(v));
+        }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        wsinv[m] = h2_pow2(-h2_shift_for(mx));
+    }
+}
+
+// image [chunk][ty][tx][piece][nt][lane][8 x f16]: lane (j = lane & 31, kg = lane >> 5) holds column nt*32 + j, k = chunk*16 + kg*8 + 0..7
+__global__ __launch_bounds__(256) void h2_pack_kernel(const float* __restrict__ w, const float* __restrict__ wsinv,
+                                                       _Float16* __restrict__ img, int cin, int cout, int nt_count,
+                                                       int transpose, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    long long r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int nt = (int)(r % nt_count); r /= nt_count;
+    const int piece = (int)(r % 2); r /= 2;
+    const int tx = (int)(r % 3); r /= 3;
+    const int ty = (int)(r % 3); r /= 3;
+    const int ch = (int)r;
+    const int m = nt * 32 + (lane & 31);
+    const int k = ch * 16 + (lane >> 5) * 8 + e;
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    _Float16 o = (_Float16)0.f;
+    if (m < M && k < K) {
+        const int tap = ty * 3 + tx;
+        const float v = transpose ? w[((long long)k * cin + m) * 9 + (8 - tap)] : w[((long long)m * cin + k) * 9 + tap];
+        const float s = v * (1.0f / wsinv[m]);          // (exact: power of two)
+        const _Float16 hi = (_Float16)s;
+        o = piece == 0 ? hi : (_Float16)(s - (float)hi);
+    }
+    img[i] = o;
+}
+
+inline int h2_pack_launch(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st) {
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    const int nt = h2_nt_for(M);
+    hipLaunchKernelGGL(h2_wscale_kernel, dim3(nt * 32), dim3(256), 0, st, w, wsinv, cin, cout, transpose);
+    SINDDM_LAUNCH_CHECK();
+    const long long total = h2_image_halfs(K, nt);
+    hipLaunchKernelGGL(h2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, wsinv,
+                       static_cast<_Float16*>(img), cin, cout, nt, transpose, total);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void conv_h2_kernel(ConvArgs p) {
+    using Cfg = H2Cfg<NT>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const sbytes = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* const sAct = sbytes;
+    unsigned char* const sW = sbytes + 2 * H2_ACT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, kg = lane >> 5;
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int Wt = p.Wt > 0 ? p.Wt : W;
+    const int nch = p.nch3;                    // 16-channel chunks
+    const int S = nch * 3;
+
+    // activation scale of this launch
+    const int xs = p.amax_in ? h2_shift_for(*p.amax_in) : 0;
+    const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
+
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int first = xcd * p.tiles_per_xcd;
+    const int last = min(first + p.tiles_per_xcd, p.ntiles);
+    const int tpi = p.tilesX * p.tilesY;
+
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w3) + (size_t)lane * 16;
+
+    for (int item = first + slot0; item < last; item += nslots) {
+        const int b = item / tpi;
+        const int tr = item - b * tpi;
+        const int tyi = tr / p.tilesX;
+        const int txi = tr - tyi * p.tilesX;
+        const int y0 = tyi * H2_TH, x0 = txi * H2_TW;
+
+        // staging map (the same for every chunk): task -> byte offset inside the chunk's planes (buffer load: an
+        // out-of-range offset reads as zero -- image border, no branch), LDS byte offset
+        constexpr int OOB = 0x40000000;
+        int goff[H2_IT], loff[H2_IT];
+#pragma unroll
+        for (int it = 0; it < H2_IT; ++it) {
+            const int idx = tid + it * 512;
+            const int kgs = idx / (H2_HR * H2_RS);
+            const int e = idx - kgs * (H2_HR * H2_RS);
+            const int r = e / H2_RS, c = e - r * H2_RS;
+            const int gy = y0 + r - 1, gx = x0 + c - 1;
+            const bool ok = idx < H2_TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            goff[it] = ok ? (kgs * 8 * HW + gy * W + gx) * 4 : OOB;
+            loff[it] = idx < H2_TASKS ? kgs * H2_PLANE + e * 16 : -1;
+        }
+        const __amdgpu_buffer_rsrc_t rsin = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.in + (size_t)b * p.Cin * HW), 0, p.Cin * HW * 4, 0x00020000);
+
+        // the chunk's staging is spread over its three (chunk, ty) sub-steps: task group `it` is loaded at the start of
+        // sub-step ty = it of the PREVIOUS chunk and split + stored at its end (8 registers in flight instead of 24)
+        float pre[8];
+        auto load_part = [&](int c, int it) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                pre[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsin, goff[it], (c * 16 + e) * HW * 4, 0));
+        };
+        auto store_part = [&](unsigned char* buf, int it) {
+            if (loff[it] < 0) return;
+            h16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = f32x2{pre[e], pre[e + 1]} * sx;
+                const h16x2 h = __builtin_convertvector(v, h16x2);
+                const f32x2 r = v - __builtin_convertvector(h, f32x2);
+                const h16x2 l = __builtin_convertvector(r, h16x2);
+                hi[e] = h[0]; hi[e + 1] = h[1];
+                lo[e] = l[0]; lo[e + 1] = l[1];
+            }
+            *reinterpret_cast<h16x8*>(buf + loff[it]) = hi;
+            *reinterpret_cast<h16x8*>(buf + loff[it] + 2 * H2_PLANE) = lo;
+        };
+        auto issue_w = [&](int s, unsigned char* slot) {
+            const unsigned char* src = wsrc + (size_t)s * Cfg::W_SLOT;
+#pragma unroll
+            for (int i = 0; i < (Cfg::W_INSTR + 7) / 8; ++i) {
+                const int k = wave + i * 8;
+                if (k < Cfg::W_INSTR)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(src + (size_t)k * 1024),
+                                                     (lds_ptr)(slot + k * 1024), 16, 0, 0);
+            }
+        };
+
+        f32x16 acc[2][NT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        issue_w(0, sW);
+#pragma unroll
+        for (int it = 0; it < H2_IT; ++it) {
+            load_part(0, it);
+            store_part(sAct, it);
+        }
+        dma_barrier();
+
+        for (int s = 0; s < S; ++s) {
+            const int c = s / 3, ty = s - c * 3;
+            if (s + 1 < S) issue_w(s + 1, sW + ((s + 1) & 1) * Cfg::W_SLOT);
+            const bool stage = c + 1 < nch;
+            if (stage) {
+                if (ty == 0) load_part(c + 1, 0);
+                else if (ty == 1) load_part(c + 1, 1);
+                else load_part(c + 1, 2);
+            }
+            const unsigned char* A = sAct + (c & 1) * H2_ACT + kg * H2_PLANE + ((wave + ty) * H2_RS + l32) * 16;
+            const unsigned char* Bw = sW + (s & 1) * Cfg::W_SLOT + lane * 16;
+            // 3 NT units (tx, n) of six MFMAs; the fragments of unit u + 1 are read from LDS before the MFMAs of unit u
+            // are issued (register double buffering, pinned: the compiler otherwise reads each fragment right before
+            // its use and the matrix pipe waits out every LDS round trip)
+            h16x8 af[2][4], bf[2][2];
+            auto ldA = [&](int tx, h16x8 (&a)[4]) {
+                a[0] = *reinterpret_cast<const h16x8*>(A + tx * 16);
+                a[1] = *reinterpret_cast<const h16x8*>(A + (32 + tx) * 16);
+                a[2] = *reinterpret_cast<const h16x8*>(A + 2 * H2_PLANE + tx * 16);
+                a[3] = *reinterpret_cast<const h16x8*>(A + 2 * H2_PLANE + (32 + tx) * 16);
+            };
+            auto ldB = [&](int tx, int n, h16x8 (&bq)[2]) {
+                bq[0] = *reinterpret_cast<const h16x8*>(Bw + ((tx * 2 + 0) * NT + n) * 1024);
+                bq[1] = *reinterpret_cast<const h16x8*>(Bw + ((tx * 2 + 1) * NT + n) * 1024);
+            };
+            ldA(0, af[0]);
+            ldB(0, 0, bf[0]);
+#pragma unroll
+            for (int u = 0; u < 3 * NT; ++u) {
+                const int tx = u / NT, n = u - tx * NT;
+                const h16x8 (&a)[4] = af[tx & 1];
+                const h16x8 (&bq)[2] = bf[u & 1];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bq[0], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], bq[0], acc[1][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // (the next unit's reads go out behind this unit's first two MFMAs: four MFMAs of this wave -- and the
+                // other wave's -- cover the LDS round trip, and the wait in front of the next unit finds them done)
+                if (u + 1 < 3 * NT) {
+                    const int tx1 = (u + 1) / NT, n1 = (u + 1) - tx1 * NT;
+                    ldB(tx1, n1, bf[(u + 1) & 1]);
+                    if (n1 == 0) ldA(tx1, af[tx1 & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[1], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[1], acc[1][n], 0, 0, 0);
+                acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bq[0], acc[0][n], 0, 0, 0);
+                acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bq[0], acc[1][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (stage) {
+                unsigned char* nb = sAct + ((c + 1) & 1) * H2_ACT;
+                if (ty == 0) store_part(nb, 0);
+                else if (ty == 1) store_part(nb, 1);
+                else store_part(nb, 2);
+            }
+            dma_barrier();
+        }
+
+        // epilogue: lane = output channel n*32 + l32, four 4-pixel groups per row tile
+        const int y = y0 + wave;
+        float amax = 0.f;
+        if (y < H) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 32 + l32;
+                if (co >= p.Cout) continue;
+                const float k = inv_sx * p.wsinv[co];
+                const float bv = p.bias ? p.bias[co] : 0.0f;
+                const size_t rowbase = ((size_t)b * p.Cout + co) * HW + (size_t)y * W;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = x0 + m * 32 + 8 * j + 4 * kg;
+                        if (x >= W) continue;
+                        const size_t o = rowbase + x;
+                        f32x4 v{acc[m][n][4 * j], acc[m][n][4 * j + 1], acc[m][n][4 * j + 2], acc[m][n][4 * j + 3]};
+                        v = v * k + bv;
+                        if (p.out_pre) *reinterpret_cast<f32x4*>(p.out_pre + o) = v;
+                        if (p.act == 1) v = gelu_erf4(v);
+                        else if (p.act == 2) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+                        }
+                        if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                        if (x + 4 > Wt) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = x + e < Wt ? v[e] : 0.0f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[e]));
+                        *reinterpret_cast<f32x4*>(p.out + o) = v;
+                    }
+            }
+        }
+        if (p.amax_out) amax_publish(amax, p.amax_out);
+    }
+}
+
+// launches with at least this many 8x64 items per CU take the kernel
+#ifndef SINDDM_H2_MIN_ITEMS_PER_CU
+#define SINDDM_H2_MIN_ITEMS_PER_CU 2
+#endif
+#ifndef SINDDM_CONV_H2
+#define SINDDM_CONV_H2 1
+#endif
+
+// Run-time switch (process-global, sinddm_debug_set_h2): 0 = the launches stay on the fp32-MFMA Winograd kernels.  For
+// A/B measurements and parity tests of both paths in one process; the library itself never changes it.
+inline int& conv_h2_flag() {
+    static int on = 1;
+    return on;
+}
+
+inline bool conv_h2_applies(int B, int H, int W, int cin, int cout) {
+    if (!SINDDM_CONV_H2 || !conv_h2_flag() || !h2_shape_ok(cin, cout) || W % 4 != 0) return false;
+    if ((long long)cin * H * W * 4 >= 0x40000000LL) return false;      // (one sample's input is addressed as a 32-bit buffer)
+    return (long long)B * ((W + H2_TW - 1) / H2_TW) * ((H + H2_TH - 1) / H2_TH) >=
+           (long long)SINDDM_H2_MIN_ITEMS_PER_CU * wino2_cu_count();
+}
+
+inline int conv_h2_launch(const ConvArgs& a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (!h2_shape_ok(a.Cin, a.Cout) || a.W % 4 != 0 || !a.wsinv || (long long)a.Cin * a.H * a.W * 4 >= 0x40000000LL)
+        return SINDDM_E_BADSHAPE;
+    ConvProfiler& prof = conv_profiler();
+    const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
+    if (rec) {
+        while (prof.created <= prof.used) {
+            (void)hipEventCreate(&prof.ev[2 * prof.created]);
+            (void)hipEventCreate(&prof.ev[2 * prof.created + 1]);
+            ++prof.created;
+        }
+        (void)hipEventRecord(prof.ev[2 * prof.used], st);
+    }
+    a.nch3 = a.Cin / 16;
+    a.tilesX = (a.W + H2_TW - 1) / H2_TW;
+    a.tilesY = (a.H + H2_TH - 1) / H2_TH;
+    a.ntiles = a.B * a.tilesX * a.tilesY;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    int wpx = wino2_cu_count() / 8;
+    if (wpx < 1) wpx = 1;
+    if (wpx > a.tiles_per_xcd) wpx = a.tiles_per_xcd;
+    const unsigned grid = (unsigned)(wpx * 8);
+    const int nt = h2_nt_for(a.Cout);
+#define H2_GO(NTV)                                                                                                      \
+    do {                                                                                                                \
+        constexpr int lds = H2Cfg<NTV>::LDS;                                                                            \
+        static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<NTV>),      \
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);        \
+        if (attr_rc != hipSuccess) return (int)attr_rc;                                                                 \
+        hipLaunchKernelGGL((conv_h2_kernel<NTV>), dim3(grid), dim3(512), lds, st, a);                                   \
+    } while (0)
+    if (nt == 5) H2_GO(5);
+    else H2_GO(3);
+#undef H2_GO
+    if (rec) {
+        (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
+        const double fl = 2.0 * a.B * a.H * (a.Wt > 0 ? a.Wt : a.W) * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        // executed: three binary16 MFMA terms per fp32 product, on whole 8x64 items and NT*32 output channels
+        prof.note(1, fl, 2.0 * a.ntiles * (H2_TH * H2_TW) * (nt * 32.0) * 9.0 * a.Cin * 3.0, 7);
+    }
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sinddm

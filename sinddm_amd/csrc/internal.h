@@ -45,12 +45,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
 // one SinDDMConvBlock forward (sinddm_fwd.hip); `cond` = the block's per-sample bias rows, stride in floats
 int block_forward(const NetPlan& P, int l, const float* params, const float* packed, const float* cur, const float* cond,
                   int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st,
-                  int Wt = 0);
+                  int Wt = 0, float* amax = nullptr);
 // which kernel generation a dim -> dim 3x3 conv launch of this shape takes: 4 / 3 = F(2x4) conv_wino4 / conv_wino3,
 // 2 = F(2x2) conv_wino2 / conv_wino, 0 = direct implicit GEMM
 int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W);
 
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
-                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi = 0, int po = 0);
+                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi = 0, int po = 0,
+                  float* amax = nullptr);
 
 }  // namespace sinddm

@@ -16,6 +16,14 @@ constexpr int KC = 8;          // input channels per LDS chunk (two k-steps of t
 constexpr int TIME_DIM = 32;   // models.py:101
 constexpr int CHANNELS = 3;
 
+// conv_h2.h (binary16 hi/lo direct conv): packed image [chunk of 16 ci][ty][tx][piece][n-tile of 32 co][lane][8 x f16]
+inline int h2_nt_for(int cout) { return (cout + 31) / 32; }
+inline long long h2_image_halfs(int cin, int nt) { return (long long)(cin / 16) * 9 * 2 * nt * 64 * 8; }
+inline bool h2_shape_ok(int cin, int cout) {
+    const int nt = h2_nt_for(cout);
+    return cin >= 16 && cin % 16 == 0 && (nt == 3 || nt == 5);
+}
+
 struct BlockPlan {
     int cin, cout;
     // flat parameter offsets (floats)
@@ -36,6 +44,8 @@ struct BlockPlan {
     int64_t pk_w1f, pk_w2f;
     // Winograd F(4x4,3x3) images of conv_wino6.h ([coblk][chunk][wave (a,b)][ks][q 0..11][lane][4]); -1 = shape not supported
     int64_t pk_w1g, pk_w2g;
+    // conv_h2.h images (float offsets; 16-byte aligned) and their per-output-channel 2^-e arrays; -1 = shape not supported
+    int64_t pk_h1, pk_h2, pk_hs1, pk_hs2;
     int cond_off;  // offset of this block's per-sample bias inside the cond vector
 };
 
@@ -112,6 +122,15 @@ inline NetPlan make_plan(int dim) {
         // (49152 floats per (co-block, chunk): 4 waves x 4 k-steps x 12 groups x 64 lanes x 4; two chunks at least)
         if (SINDDM_WINO_F44_BUILD && f24 && b.cin >= 32 && b.cin % 16 == 0) { b.pk_w1g = q; q += (int64_t)b.coblks * b.nchw1 * 49152; } else b.pk_w1g = -1;
         if (SINDDM_WINO_F44_BUILD && f24 && b.cout >= 32 && b.cout % 16 == 0) { b.pk_w2g = q; q += (int64_t)b.coblks * b.nchw2 * 49152; } else b.pk_w2g = -1;
+        q = (q + 63) / 64 * 64;
+        if (h2_shape_ok(b.cin, b.cout)) {
+            b.pk_h1 = q; q += h2_image_halfs(b.cin, h2_nt_for(b.cout)) / 2;
+            b.pk_hs1 = q; q += h2_nt_for(b.cout) * 32;
+        } else b.pk_h1 = b.pk_hs1 = -1;
+        if (h2_shape_ok(b.cout, b.cout)) {
+            b.pk_h2 = q; q += h2_image_halfs(b.cout, h2_nt_for(b.cout)) / 2;
+            b.pk_hs2 = q; q += h2_nt_for(b.cout) * 32;
+        } else b.pk_h2 = b.pk_hs2 = -1;
         b.cond_off = coff;
         coff += b.cin;
     }

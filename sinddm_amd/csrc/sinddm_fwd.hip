@@ -3,6 +3,7 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino4.h"
+#include "conv_h2.h"
 #include "internal.h"
 #if SINDDM_WINO_F44_BUILD
 #include "conv_wino6.h"
@@ -261,10 +262,25 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
             addf(wz);
         }
     }
-    if (n == 0) return 0;
-    f.nseg = n;
-    f.total = total;
-    return pack_launch(params, packed, f, st);
+    if (n > 0) {
+        f.nseg = n;
+        f.total = total;
+        rc = pack_launch(params, packed, f, st);
+        if (rc) return rc;
+    }
+    // the binary16 hi/lo images of conv_h2.h and their per-channel scales
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        if (b.pk_h1 >= 0) {
+            rc = h2_pack_launch(params + b.c1_w, packed + b.pk_hs1, packed + b.pk_h1, b.cin, b.cout, 0, st);
+            if (rc) return rc;
+        }
+        if (b.pk_h2 >= 0) {
+            rc = h2_pack_launch(params + b.c2_w, packed + b.pk_hs2, packed + b.pk_h2, b.cout, b.cout, 0, st);
+            if (rc) return rc;
+        }
+    }
+    return 0;
 }
 
 // =====================================================================================
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
                                                        const float* __restrict__ bias, const float* __restrict__ cond,
                                                        int cond_stride, const float* __restrict__ addt, int flip,
                                                        float* __restrict__ out, int C, int H, int W, int groupsX, int pi,
-                                                       int po) {
+                                                       int po, float* __restrict__ amax) {
     // pi / po: row pitch of the input / output planes (floats; = W for plain tensors).  po > W: the library's padded
     // workspace layout -- columns W .. po-1 are written as zeros (the 3x3 convs that read them rely on it)
     __shared__ __attribute__((aligned(16))) float tile[DW_NX][DW_HR * DW_RS];
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
     const float add = (bias ? bias[c] : 0.0f) + (cond ? cond[(size_t)b * cond_stride + c] : 0.0f);
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mx = 0.f;
 #pragma unroll
     for (int t = 0; t < DW_NX; ++t) {
         const int x0 = xg0 + t * DW_TW;
@@ -455,12 +472,15 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
                     const int gy = y0 + wv * DW_RW + r;
                     if (gy < H) {
                         const size_t oidx = plane + (size_t)gy * po + gx;
-                        out[oidx] = gx < W ? (addt ? o[r][h] + addt[oidx] : o[r][h]) : 0.0f;
+                        const float ov = gx < W ? (addt ? o[r][h] + addt[oidx] : o[r][h]) : 0.0f;
+                        mx = fmaxf(mx, fabsf(ov));
+                        out[oidx] = ov;
                     }
                 }
             }
         }
     }
+    if (amax) amax_publish(mx, amax);
 }
 
 // Register-window variant for rows that are a multiple of 4 pixels (16-byte aligned): no LDS, no barrier.  A lane owns 4
@@ -476,7 +496,8 @@ constexpr int DWR_ROWS = DWR_ROWS_;
 __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ cond,
                                                             int cond_stride, const float* __restrict__ addt, int flip,
-                                                            float* __restrict__ out, int C, int H, int W, int bandsX, int Wt) {
+                                                            float* __restrict__ out, int C, int H, int W, int bandsX, int Wt,
+                                                            float* __restrict__ amax) {
     // Wt: true width when the rows are padded to W (input pads hold zeros, output pads are written as zeros); else = W
     const int c = blockIdx.y, b = blockIdx.z;
     const int by = blockIdx.x / bandsX, bx = blockIdx.x - by * bandsX;
@@ -518,11 +539,11 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
             }
         }
     }
-    if (!colok) return;
+    float mx = 0.f;
 #pragma unroll
     for (int r = 0; r < DWR_ROWS; ++r) {
         const int gy = y0 + r;
-        if (gy < H) {
+        if (colok && gy < H) {
             const size_t o = plane + (size_t)gy * W + x4;
             f32x4 v = acc[r];
             if (addt) v += *reinterpret_cast<const f32x4*>(addt + o);
@@ -530,9 +551,11 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) v[cc] = x4 + cc < Wt ? v[cc] : 0.0f;
             }
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
             *reinterpret_cast<f32x4*>(out + o) = v;
         }
     }
+    if (amax) amax_publish(mx, amax);          // (every lane of a live wave gets here: no divergent exit above)
 }
 
 #ifndef SINDDM_DW_ROWS
@@ -541,20 +564,21 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
 
 // pi / po: row pitch of the input / output planes (0 = W).  po > W: padded workspace rows, pads written as zeros.
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
-                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi, int po) {
+                  const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi, int po,
+                  float* amax) {
     if (pi <= 0) pi = W;
     if (po <= 0) po = W;
     if (SINDDM_DW_ROWS && pi % 4 == 0 && po == pi && pi >= 192) {   // (a lane owns 4 columns: narrow images leave most of a wave idle)
         const int bandsX = (pi + 255) / 256, bandsY = (H + 4 * DWR_ROWS - 1) / (4 * DWR_ROWS);
         hipLaunchKernelGGL(dwconv5_rows_kernel, dim3(bandsX * bandsY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                           addt, flip, out, C, H, pi, bandsX, W);
+                           addt, flip, out, C, H, pi, bandsX, W, amax);
         SINDDM_LAUNCH_CHECK();
         return 0;
     }
     const int tilesX = (W + DW_TW - 1) / DW_TW, tilesY = (H + DW_TH - 1) / DW_TH;
     const int groupsX = (tilesX + DW_NX - 1) / DW_NX;
     hipLaunchKernelGGL(dwconv5_kernel, dim3(groupsX * tilesY, C, B), dim3(256), 0, st, x, w, bias, cond, cond_stride,
-                       addt, flip, out, C, H, W, groupsX, pi, po);
+                       addt, flip, out, C, H, W, groupsX, pi, po, amax);
     SINDDM_LAUNCH_CHECK();
     return 0;
 }
@@ -570,7 +594,7 @@ int dwconv_launch(const float* x, const float* w, const float* bias, const float
 __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               float* __restrict__ out_pre, int H, int W, int Cout,
-                                                              int co_per_block, int Wt) {
+                                                              int co_per_block, int Wt, float* __restrict__ amax) {
     // Wt: true width when the rows are padded to W (pads: zeros in, zeros out); else = W
     const int HW = H * W;
     const int b = blockIdx.y;
@@ -613,6 +637,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
     };
     // (two output channels per iteration: their GELUs run as one packed sequence)
     int co = co0;
+    float mx = 0.f;
 #pragma unroll 2
     for (; co + 1 < co1; co += 2) {
         const f32x2 acc{dot27(co), dot27(co + 1)};
@@ -622,17 +647,22 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
                 dpre[(size_t)(co + 1) * HW] = acc.y;
             }
             const f32x2 g = gelu_erf2(acc);
-            dst[(size_t)co * HW] = x < Wt ? g.x : 0.0f;
-            dst[(size_t)(co + 1) * HW] = x < Wt ? g.y : 0.0f;
+            const float g0 = x < Wt ? g.x : 0.0f, g1 = x < Wt ? g.y : 0.0f;
+            mx = fmaxf(mx, fmaxf(fabsf(g0), fabsf(g1)));
+            dst[(size_t)co * HW] = g0;
+            dst[(size_t)(co + 1) * HW] = g1;
         }
     }
     if (co < co1) {
         const float acc = dot27(co);
         if (live) {
             if (dpre) dpre[(size_t)co * HW] = acc;
-            dst[(size_t)co * HW] = x < Wt ? gelu_erf(acc) : 0.0f;
+            const float g0 = x < Wt ? gelu_erf(acc) : 0.0f;
+            mx = fmaxf(mx, fabsf(g0));
+            dst[(size_t)co * HW] = g0;
         }
     }
+    if (amax) amax_publish(mx, amax);
 }
 
 // =====================================================================================
@@ -1005,9 +1035,12 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // conditioning rows: one per sample (sinddm_net_forward) or one per sampler step of a run (sinddm_sample_chain: every
 // sample of the batch shares the step's t, so a whole run of steps is embedded by ONE cond_kernel launch)
 constexpr int CHAIN_COND_ROWS = 1024;
+// ... followed by the eight running-max scalars of one network evaluation (conv_h2.h: slot 2 l + i = max |input| of conv
+// i of block l, maintained by that tensor's producer kernel, zeroed at the start of the evaluation)
+constexpr size_t AMAX_REGION = 256;
 static size_t cond_region_bytes(const NetPlan& P, int B) {
     const int rows = B > CHAIN_COND_ROWS ? B : CHAIN_COND_ROWS;
-    return align_up((size_t)rows * P.cond_stride * sizeof(float), 256);
+    return align_up((size_t)rows * P.cond_stride * sizeof(float), 256) + AMAX_REGION;
 }
 #ifndef SINDDM_PITCH
 #define SINDDM_PITCH 1        // 1: inference keeps its activations with rows padded to a multiple of 4 floats (W % 4 != 0 scales)
@@ -1054,12 +1087,16 @@ int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W) {
 // Wt > 0: padded workspace rows -- every tensor here (cur included) has row pitch W (a multiple of 4) and true width Wt.
 int block_forward(const NetPlan& P, int l, const float* params, const float* packed, const float* cur, const float* cond,
                   int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st,
-                  int Wt) {
+                  int Wt, float* amax) {
     const BlockPlan& b = P.blk[l];
+    // binary16 hi/lo direct kernel (conv_h2.h): inference launches with a few 8x64 items per CU; `amax` = this block's two
+    // running-max scalars (input of conv1, input of conv2), maintained by the kernels that produce those tensors
+    const bool h2a = amax && b.pk_h1 >= 0 && conv_h2_applies(B, H, W, b.cin, b.cout);
+    const bool h2b = amax && b.pk_h2 >= 0 && conv_h2_applies(B, H, W, b.cout, b.cout);
     int rc = Wt > 0 ? dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
-                                    Wt, st, W, W)
+                                    Wt, st, W, W, h2a ? amax : nullptr)
                     : dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
-                                    W, st);
+                                    W, st, 0, 0, h2a ? amax : nullptr);
     if (rc) return rc;
     const bool wino = wino_enabled();
     ConvArgs c1{};
@@ -1076,7 +1113,11 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     // ... and, where the image exists and the row pitch allows, its F(4x4) successor (a quarter of the MFMAs gone)
     const bool v6a = v4 && b.pk_w1g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cin);
     const bool v6b = v4 && b.pk_w2g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cout);
-    if (v6a) {
+    if (h2a) {
+        c1.w3 = packed + b.pk_h1; c1.wsinv = packed + b.pk_hs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
+        c1.bias = params + b.c1_b;
+        rc = conv_h2_launch(c1, st);
+    } else if (v6a) {
         c1.w3 = packed + b.pk_w1g; c1.nch3 = b.nchw1;
         rc = conv_wino6_launch(c1, st);
     } else if (v3 && b.pk_w1f >= 0) {
@@ -1091,7 +1132,8 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         int split = 1;                                       // channel groups: aim at >= ~2048 workgroups
         while (split < 8 && nwg * split < 2048 && b.cout % (split * 2) == 0) split *= 2;
         hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B, split), dim3(256), 0, st, hbuf,
-                           params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split, Wt > 0 ? Wt : W);
+                           params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split, Wt > 0 ? Wt : W,
+                           h2b ? amax + 1 : nullptr);
         SINDDM_LAUNCH_CHECK();
         rc = 0;
     } else {
@@ -1117,7 +1159,10 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
             c2.resid = cur; c2.bias = packed + b.pk_b2;
         }
         c2.nch1 = 0;
-        if (v6b) {
+        if (h2b) {
+            c2.w3 = packed + b.pk_h2; c2.wsinv = packed + b.pk_hs2; c2.amax_in = amax + 1;
+            rc = conv_h2_launch(c2, st);
+        } else if (v6b) {
             c2.w3 = packed + b.pk_w2g; c2.nch3 = b.nchw2;
             rc = conv_wino6_launch(c2, st);
         } else if (v3 && b.pk_w2f >= 0) {
@@ -1141,6 +1186,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
                      hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
     FwdBuffers fb{};
     float* xpad = nullptr;
+    float* amax = nullptr;       // eight running-max scalars (conv_h2.h); inference only
     if (tb) {
         fb.cond = tb->cond;
     } else {
@@ -1148,6 +1194,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         char* base = static_cast<char*>(ws);
         fb.cond = reinterpret_cast<float*>(base);
         base += cond_region_bytes(P, B);
+        amax = reinterpret_cast<float*>(base - AMAX_REGION);
         const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
         for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
         xpad = reinterpret_cast<float*>(base + 4 * act);
@@ -1174,6 +1221,9 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         SINDDM_LAUNCH_CHECK();
     }
 
+    if (amax && SINDDM_CONV_H2) {
+        if (hipMemsetAsync(amax, 0, 8 * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
+    }
     const float* cur = x;
     if (padded) {
         const long long nrows = (long long)B * CHANNELS * H;
@@ -1194,7 +1244,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         float* gbuf = tb ? tb->g[l] : fb.buf[sel[1]];
         float* obuf = tb ? tb->o[l] : fb.buf[sel[2]];
         const int rc = block_forward(P, l, params, packed, cur, fb.cond + b.cond_off, cond_stride, hbuf, gbuf, obuf,
-                                     tb ? tb->u[l] : nullptr, B, H, Wp, st, padded ? W : 0);
+                                     tb ? tb->u[l] : nullptr, B, H, Wp, st, padded ? W : 0, amax ? amax + 2 * l : nullptr);
         if (rc) return rc;
         cur = obuf;
         curb = sel[2];
@@ -1522,6 +1572,22 @@ int sinddm_prof_end(double* conv_ms_total, int64_t* conv_launches, double* conv_
 int sinddm_prof_end2(double* conv_ms_total, int64_t* conv_launches, double* conv_flops_total,
                      double* conv_exec_flops_total) {
     return sinddm_prof_end3(0, conv_ms_total, conv_launches, conv_flops_total, conv_exec_flops_total, 1);
+}
+
+int sinddm_debug_infer_path(int dim, int B, int H, int W) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    const BlockPlan& b = p.blk[2];                      // the dim -> dim block
+    const int Wp = fwd_pitch(W);
+    if (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout)) return 7;
+    return conv3x3_path(b.cout, b.cout, b.coblks, B, H, Wp);
+}
+
+int sinddm_debug_set_h2(int on) {
+    int& f = conv_h2_flag();
+    const int prev = f;
+    f = on != 0;
+    return prev;
 }
 
 int sinddm_debug_set_f44(int on) {

@@ -1,0 +1,128 @@
+"""GPU parity of conv_h2.h -- the 3x3 convolutions of inference launches as a direct implicit GEMM on the binary16 matrix
+pipe with every fp32 operand split into two binary16 pieces (three MFMA terms per product, fp32 accumulate, exact
+power-of-two operand scales from the weights' per-channel max and the activation tensor's running max).
+
+The gate: the kernel must not be narrower than fp32.  Every evaluation is compared with the FLOAT64
+oracle and its error is held against the error of the fp32 oracle (torch CPU fp32 = the reference's own arithmetic) on the
+same inputs: <= 1.5 x.  Also: against the fp32-MFMA Winograd path of the same library (sinddm_debug_set_h2(0)), ragged
+widths (padded rows), tile rows cut by the image edge, C_out = 80 (padded to 96 columns) and 160, dynamic-range stress
+(activations scaled by 2^-12 and 2^+10: the running-max scale must keep binary16 in range), a fused sampler chain.
+reference SinDDM/models.py:63,65 (the 3x3 convolutions), :69-80 (the block)
+"""
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import sinddm_oracle as O
+from sinddm_amd.synth import closed_form_state_dict, hash_randn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from sinddm_amd import _lib
+    return _lib.load()
+
+
+def _net(dim=160, sd=None):
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(sd if sd is not None else closed_form_state_dict(dim))
+    return net
+
+
+def _net_forward_f64(sd, x, t, scale):
+    """The oracle's network in float64 (the conditioning vector comes from the fp32 oracle: it is not what is tested)."""
+    cond = O.cond_vector(sd, t, scale).double()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    h = x.double()
+    for name in ("l1", "l2", "l3", "l4"):
+        h = O.conv_block(sd64, name, h, cond)
+    return torch.nn.functional.conv2d(h, sd64["final_conv.0.weight"], sd64["final_conv.0.bias"])
+
+
+@pytest.fixture
+def h2_switch():
+    lib = _lib()
+    prev = lib.sinddm_debug_set_h2(1)
+    yield lib
+    lib.sinddm_debug_set_h2(prev)
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 186, 248),      # C2 finest: W % 4 == 0, H % 8 = 2
+                                    (12, 133, 177),     # odd width: rows padded to 180, last item 52 columns wide
+                                    (3, 411, 512),      # C3 finest, exact 64-column items, H % 8 = 3
+                                    (24, 94, 126)])     # W % 4 = 2
+def test_error_vs_float64_not_wider_than_fp32(h2_switch, B, H, W):
+    lib = h2_switch
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 7
+    sd = closed_form_state_dict(160)
+    net = _net(160, sd)
+    x = hash_randn((B, 3, H, W), 1234 + W) * 0.9
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    idx = [0, B - 1]
+    got = net.infer(x.to(DEV), t.to(DEV), 0, 2.0).cpu()
+    ref64 = _net_forward_f64(sd, x[idx], t[idx], 2)
+    ref32 = O.net_forward(sd, x[idx], t[idx], 2)
+    e_h2 = rel_l2(got[idx], ref64)
+    e_32 = rel_l2(ref32, ref64)
+    lib.sinddm_debug_set_h2(0)
+    assert lib.sinddm_debug_infer_path(160, B, H, W) != 7
+    got_w = net.infer(x.to(DEV), t.to(DEV), 0, 2.0).cpu()
+    lib.sinddm_debug_set_h2(1)
+    e_w = rel_l2(got_w[idx], ref64)
+    print(f"[h2] {B}x{H}x{W}: vs float64  h2 {e_h2:.3e}  fp32-MFMA Winograd {e_w:.3e}  fp32 oracle {e_32:.3e};"
+          f"  h2 vs Winograd {rel_l2(got, got_w):.3e}")
+    assert rel_l2(got[idx], ref32) < 1e-5                  # the tolerance every net-forward parity test uses
+    assert e_h2 <= 1.5 * e_32, (e_h2, e_32)
+    assert rel_l2(got, got_w) < 5e-6
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("gain", [2.0 ** -12, 2.0 ** 10])
+def test_dynamic_range(h2_switch, gain):
+    """Activations far from 1: the first block's output is scaled by `gain` (weights of l1.net.2 and its residual projection),
+    so every later 3x3 conv sees inputs around `gain`.  The running-max scale must keep both binary16 pieces in range:
+    same relative error as at gain 1."""
+    lib = h2_switch
+    B, H, W = 8, 186, 248
+    sd = {k: v.clone() for k, v in closed_form_state_dict(160).items()}
+    for k in ("l1.net.2.weight", "l1.net.2.bias", "l1.res_conv.weight", "l1.res_conv.bias"):
+        sd[k] = sd[k] * gain
+    for k in ("l2.ds_conv.bias", "l2.time_reshape.weight", "l2.time_reshape.bias"):
+        sd[k] = sd[k] * gain
+    net = _net(160, sd)
+    x = hash_randn((B, 3, H, W), 99) * 0.9
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    idx = [0, B - 1]
+    got = net.infer(x.to(DEV), t.to(DEV), 0, 1.0).cpu()
+    ref64 = _net_forward_f64(sd, x[idx], t[idx], 1)
+    ref32 = O.net_forward(sd, x[idx], t[idx], 1)
+    e_h2, e_32 = rel_l2(got[idx], ref64), rel_l2(ref32, ref64)
+    print(f"[h2] gain {gain:g}: vs float64  h2 {e_h2:.3e}  fp32 oracle {e_32:.3e}")
+    assert torch.isfinite(got).all()
+    assert e_h2 <= 1.5 * e_32, (e_h2, e_32)
+
+
+def test_fused_chain_h2_vs_winograd(h2_switch):
+    """The production sampler call (sinddm_sample_chain: in-kernel Philox, fused tail) for 12 steps at the C2 finest scale,
+    batch 16, with the kernel on and off: same seed -> same noise, so the two runs differ by the convs' rounding only."""
+    lib = h2_switch
+    from sinddm_amd.configs import build_diffusion
+    net, d = build_diffusion("C2", dim=160, device=torch.device(DEV))
+    s = 4
+    H, W = d.target_size(s, (1, 1), True, s)
+    B = 16
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 7
+    x0 = hash_randn((B, 3, H, W), 5150).to(DEV)
+    d.img_prev_upsample = (hash_randn((B, 3, H, W), 5151) * 0.5).clamp(-1, 1).to(DEV)
+    outs = []
+    for on in (1, 0):
+        lib.sinddm_debug_set_h2(on)
+        torch.manual_seed(7)
+        outs.append(d._run_steps(x0.clone(), s, list(range(40, 28, -1))).cpu())
+    lib.sinddm_debug_set_h2(1)
+    err = rel_l2(outs[0], outs[1])
+    print(f"[h2] 12 fused steps, h2 vs fp32-MFMA Winograd: {err:.3e}")
+    assert err < 2e-5

@@ -19,6 +19,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _fp32_mfma_path():
+    """Inference launches of these shapes default to conv_h2 (tests/test_gpu_h2.py); conv_wino4 stays the kernel of the
+    training forward / data gradients and of the switch-off path: keep it under test."""
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    prev = lib.sinddm_debug_set_h2(0)
+    yield
+    lib.sinddm_debug_set_h2(prev)
+
+
 def _path(B, H, W):
     """Kernel generation the dim -> dim 3x3 convolutions of a launch of this shape take (both forward and data gradient)."""
     from sinddm_amd import _lib
