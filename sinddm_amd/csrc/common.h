@@ -56,6 +56,10 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// conv_h2.h: running max |x| of the tensors the binary16 kernel reads, PER SAMPLE ([B][AMAX_STRIDE] floats, slot 2 l + i =
+// input of conv i of block l): a sample's scale -- and so its result, bit for bit -- does not depend on what else is in the batch
+constexpr int AMAX_STRIDE = 8;
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 

@@ -9,8 +9,9 @@
 // binary16 has 5 exponent bits, so both operands are brought to a known range by EXACT power-of-two scales that the
 // epilogue removes again:
 //   * weights: per output channel, 2^e with max|w| * 2^e in [2^13, 2^14), chosen when the weights are packed;
-//   * activations: per launch, from the running max |x| of the tensor (`amax_in`, a device scalar its producer kernel
-//     maintains with one guarded atomicMax per wave); scaled max in [2^13, 2^14).
+//   * activations: per SAMPLE, from the running max |x| of the sample's tensor (`amax_in[b * AMAX_STRIDE]`, a device scalar
+//     its producer kernel maintains with one guarded atomicMax per wave); scaled max in [2^13, 2^14).  Per sample, so that a
+//     chain's numbers do not depend on the rest of its batch (shards of a multi-GPU job reproduce the single-GPU run).
 // Pieces that fall below the binary16 normal range lose at most 2^-25 absolute = 2^-38 of the tensor's max.
 //
 // GEMM view: rows = 32 consecutive pixels of an image row (A operand, from the activation tile in LDS), columns = 32
@@ -160,10 +161,6 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(ConvArgs p) {
     const int nch = p.nch3;                    // 16-channel chunks
     const int S = nch * 3;
 
-    // activation scale of this launch
-    const int xs = p.amax_in ? h2_shift_for(*p.amax_in) : 0;
-    const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
-
     const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int first = xcd * p.tiles_per_xcd;
     const int last = min(first + p.tiles_per_xcd, p.ntiles);
@@ -177,6 +174,9 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(ConvArgs p) {
         const int tyi = tr / p.tilesX;
         const int txi = tr - tyi * p.tilesX;
         const int y0 = tyi * H2_TH, x0 = txi * H2_TW;
+        // activation scale of this sample
+        const int xs = p.amax_in ? h2_shift_for(p.amax_in[(size_t)b * AMAX_STRIDE]) : 0;
+        const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
 
         // staging map (the same for every chunk): task -> byte offset inside the chunk's planes (buffer load: an
         // out-of-range offset reads as zero -- image border, no branch), LDS byte offset
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(ConvArgs p) {
                     }
             }
         }
-        if (p.amax_out) amax_publish(amax, p.amax_out);
+        if (p.amax_out) amax_publish(amax, p.amax_out + (size_t)b * AMAX_STRIDE);
     }
 }
 

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void dwconv5_kernel(const float* __restrict__ 
             }
         }
     }
-    if (amax) amax_publish(mx, amax);
+    if (amax) amax_publish(mx, amax + (size_t)b * AMAX_STRIDE);
 }
 
 // Register-window variant for rows that are a multiple of 4 pixels (16-byte aligned): no LDS, no barrier.  A lane owns 4
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void dwconv5_rows_kernel(const float* __restri
             *reinterpret_cast<f32x4*>(out + o) = v;
         }
     }
-    if (amax) amax_publish(mx, amax);          // (every lane of a live wave gets here: no divergent exit above)
+    if (amax) amax_publish(mx, amax + (size_t)b * AMAX_STRIDE);          // (every lane of a live wave gets here: no divergent exit above)
 }
 
 #ifndef SINDDM_DW_ROWS
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_gelu_kernel(const float* __res
             dst[(size_t)co * HW] = g0;
         }
     }
-    if (amax) amax_publish(mx, amax);
+    if (amax) amax_publish(mx, amax + (size_t)b * AMAX_STRIDE);
 }
 
 // =====================================================================================
@@ -1035,30 +1035,44 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // conditioning rows: one per sample (sinddm_net_forward) or one per sampler step of a run (sinddm_sample_chain: every
 // sample of the batch shares the step's t, so a whole run of steps is embedded by ONE cond_kernel launch)
 constexpr int CHAIN_COND_ROWS = 1024;
-// ... followed by the eight running-max scalars of one network evaluation (conv_h2.h: slot 2 l + i = max |input| of conv
-// i of block l, maintained by that tensor's producer kernel, zeroed at the start of the evaluation)
-constexpr size_t AMAX_REGION = 256;
+// ... followed by the running-max scalars of one network evaluation (conv_h2.h: [sample][AMAX_STRIDE], slot 2 l + i = max
+// |input| of conv i of block l, maintained by that tensor's producer kernel, zeroed at the start of the evaluation)
+static size_t amax_region_bytes(int B) { return ((size_t)B * AMAX_STRIDE * sizeof(float) + 255) / 256 * 256; }
 static size_t cond_region_bytes(const NetPlan& P, int B) {
     const int rows = B > CHAIN_COND_ROWS ? B : CHAIN_COND_ROWS;
-    return align_up((size_t)rows * P.cond_stride * sizeof(float), 256) + AMAX_REGION;
+    return align_up((size_t)rows * P.cond_stride * sizeof(float), 256) + amax_region_bytes(B);
 }
 #ifndef SINDDM_PITCH
 #define SINDDM_PITCH 1        // 1: inference keeps its activations with rows padded to a multiple of 4 floats (W % 4 != 0 scales)
 #endif
 // row pitch of the library's own activation buffers in inference: W rounded up to 4 floats
-static int fwd_pitch(int W) { return (SINDDM_PITCH && W % 4 != 0) ? (W + 3) / 4 * 4 : W; }
-static size_t fwd_xpad_bytes(int B, int H, int W) {        // padded copy of the network input (only when the pitch differs)
-    return fwd_pitch(W) != W ? align_up((size_t)B * CHANNELS * H * fwd_pitch(W) * sizeof(float), 256) : 0;
+// Padded rows need every producer to write the pad columns as zeros (ConvArgs::Wt): the depthwise kernels, the C_in = 3
+// conv, the Winograd kernels of conv_wino2/3/4.h and conv_h2 do; the direct implicit-GEMM kernel (conv_mfma.h) and the
+// first-generation Winograd kernel do not.  So the pitch is a property of the PLAN: rows are padded only when
+// block_forward routes every 3x3 conv of the network to a Wt-aware kernel (all channel counts multiples of 4, C_in = 3 or
+// >= 8) -- other widths (--dim 10, 20, 28 ...) keep plain rows and the kernels' edge variants.
+static bool plan_pads_rows(const NetPlan& P) {
+    if (!SINDDM_PITCH || !wino_enabled() || !SINDDM_WINO_V2 || !SINDDM_CONV_C3) return false;
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        if (b.cout % 4 != 0) return false;
+        if (b.cin != 3 && !(b.pk_wc1 >= 0 && b.cin % 4 == 0)) return false;
+    }
+    return true;
+}
+static int fwd_pitch(const NetPlan& P, int W) { return (W % 4 != 0 && plan_pads_rows(P)) ? (W + 3) / 4 * 4 : W; }
+static size_t fwd_xpad_bytes(const NetPlan& P, int B, int H, int W) {        // padded copy of the network input (only when the pitch differs)
+    return fwd_pitch(P, W) != W ? align_up((size_t)B * CHANNELS * H * fwd_pitch(P, W) * sizeof(float), 256) : 0;
 }
 // what one network evaluation of batch B carves from its workspace: conditioning rows, 4 activation buffers, padded input
 static size_t fwd_workspace_core(const NetPlan& P, int B, int H, int W) {
-    const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
-    return cond_region_bytes(P, B) + 4 * act + fwd_xpad_bytes(B, H, W);
+    const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(P, W) * sizeof(float), 256);
+    return cond_region_bytes(P, B) + 4 * act + fwd_xpad_bytes(P, B, H, W);
 }
 // ... and what sinddm_workspace_bytes reports: room for a sampler run that splits the batch into two halves on two
 // streams (sinddm_sample_chain2): the shared conditioning table + two cores of half the batch
 static size_t fwd_workspace_bytes(const NetPlan& P, int B, int H, int W) {
-    return fwd_workspace_core(P, B, H, W) + 2 * cond_region_bytes(P, 1) + 4096;
+    return fwd_workspace_core(P, B, H, W) + 2 * cond_region_bytes(P, (B + 1) / 2) + 4096;
 }
 
 // sampler-run extras of net_forward_impl: the step's conditioning row (already computed, shared by the batch) and the
@@ -1194,13 +1208,13 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         char* base = static_cast<char*>(ws);
         fb.cond = reinterpret_cast<float*>(base);
         base += cond_region_bytes(P, B);
-        amax = reinterpret_cast<float*>(base - AMAX_REGION);
-        const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(W) * sizeof(float), 256);
+        amax = reinterpret_cast<float*>(base - amax_region_bytes(B));
+        const size_t act = align_up((size_t)B * P.dim * H * fwd_pitch(P, W) * sizeof(float), 256);
         for (int i = 0; i < 4; ++i) fb.buf[i] = reinterpret_cast<float*>(base + i * act);
         xpad = reinterpret_cast<float*>(base + 4 * act);
     }
     // padded rows: inference only (the training workspace keeps plain tensors: backward reads them with the plain kernels)
-    const int Wp = tb ? W : fwd_pitch(W);
+    const int Wp = tb ? W : fwd_pitch(P, W);
     const bool padded = Wp != W;
     int cond_stride = P.cond_stride;
     if (cs) { fb.cond = const_cast<float*>(cs->cond_row); cond_stride = 0; }
@@ -1222,7 +1236,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
     }
 
     if (amax && SINDDM_CONV_H2) {
-        if (hipMemsetAsync(amax, 0, 8 * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
+        if (hipMemsetAsync(amax, 0, (size_t)B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
     }
     const float* cur = x;
     if (padded) {
@@ -1417,17 +1431,20 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
     if (bx > 8192) bx = 8192;
     if (ws_bytes < fwd_workspace_bytes(p, B, H, W)) return SINDDM_E_WORKSPACE;
     float* cond_tab = static_cast<float*>(ws);                 // the conditioning region: one row per step of a run
-    const bool fuse_tail = (H * W) % 4 == 0 || fwd_pitch(W) != W;     // (padded rows: their own fused tail kernel)
+    const bool fuse_tail = (H * W) % 4 == 0 || fwd_pitch(p, W) != W;     // (padded rows: their own fused tail kernel)
     // Coarse pyramid scales: a launch carries a handful of work items per CU (C2 48x64 at batch 16: 1.5), every kernel ends
     // in a partly filled round and pays its fixed ramp / drain, and each step is a chain of 16 dependent launches.  The
     // chains of the batch are independent, so with a second stream the batch runs as TWO half-batches whose launches
     // overlap: the tail round of one fills with the other's items.  Same numbers either way (the noise is keyed on the
     // whole batch's flat index: ChainStep::b0).
-    const long long items = (long long)B * ((fwd_pitch(W) + 31) / 32) * ((H + 7) / 8) * 2;
+    const long long items = (long long)B * ((fwd_pitch(p, W) + 31) / 32) * ((H + 7) / 8) * 2;
     const long long ncu = wino2_cu_count();
     const long long rounds = (items + ncu - 1) / ncu;
-    const bool split = sx != nullptr && sx != st && B >= 2 && fuse_tail && n_steps > 0 && items < SINDDM_SPLIT_ITEMS_HI * ncu &&
-                       items >= SINDDM_SPLIT_ITEMS_LO * ncu && (rounds * ncu - items) * 25 >= rounds * ncu;
+    bool split = sx != nullptr && sx != st && B >= 2 && fuse_tail && n_steps > 0 && items < SINDDM_SPLIT_ITEMS_HI * ncu &&
+                 items >= SINDDM_SPLIT_ITEMS_LO * ncu && (rounds * ncu - items) * 25 >= rounds * ncu;
+    // (the two halves carve their own cores behind the shared conditioning table: only if that really fits -- ADVICE r4)
+    if (split && cond_region_bytes(p, B) + fwd_workspace_core(p, (B + 1) / 2, H, W) + fwd_workspace_core(p, B - (B + 1) / 2, H, W) > ws_bytes)
+        split = false;
     const int Bh[2] = {split ? (B + 1) / 2 : B, split ? B - (B + 1) / 2 : 0};
     char* wsh[2] = {static_cast<char*>(ws), nullptr};
     size_t wsz[2] = {ws_bytes, 0};
@@ -1437,9 +1454,11 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
         wsz[0] = fwd_workspace_core(p, Bh[0], H, W);
         wsh[1] = wsh[0] + wsz[0];
         wsz[1] = fwd_workspace_core(p, Bh[1], H, W);
-        if (hipEventCreateWithFlags(&ev_go, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&ev_go, hipEventDisableTiming) != hipSuccess) return SINDDM_E_BADARG;
+        if (hipEventCreateWithFlags(&ev_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipEventDestroy(ev_go);
             return SINDDM_E_BADARG;
+        }
     }
     const size_t hoff = (size_t)Bh[0] * CHANNELS * H * W;      // the second half's offset into x / x_alt / eps / x_tilde
     float* cur = x;
@@ -1463,10 +1482,10 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
             ca.cin[l] = p.blk[l].cin; ca.coff[l] = p.blk[l].cond_off;
         }
         hipLaunchKernelGGL(cond_kernel, dim3(len), dim3(128), 0, st, ca);
-        SINDDM_LAUNCH_CHECK();
+        if (hipGetLastError() != hipSuccess) { rc = SINDDM_E_BADARG; break; }      // (no early return: the events below are ours)
         if (split) {                                           // the second stream starts behind the table (and behind
-            (void)hipEventRecord(ev_go, st);                   // everything the caller enqueued before this call)
-            (void)hipStreamWaitEvent(sx, ev_go, 0);
+            // everything the caller enqueued before this call); a failed dependency must not become a silent race
+            if (hipEventRecord(ev_go, st) != hipSuccess || hipStreamWaitEvent(sx, ev_go, 0) != hipSuccess) { rc = SINDDM_E_BADARG; break; }
         }
         for (int i = i0; i < i0 + len && rc == 0; ++i) {
             if (coefs[i].mode != 0 && !x_tilde) { rc = SINDDM_E_BADARG; break; }
@@ -1489,8 +1508,12 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
             float* t_ = cur; cur = nxt; nxt = t_;
         }
         if (split) {                                           // the caller's stream continues behind both halves (and the
-            (void)hipEventRecord(ev_done, sx);                 // next run's table is not written under the second half)
-            (void)hipStreamWaitEvent(st, ev_done, 0);
+            // next run's table is not written under the second half) -- ALSO when a launch failed mid-run: the caller
+            // frees x / x_alt / eps on the error path, the work already queued on the second stream must be behind `st`
+            if (hipEventRecord(ev_done, sx) != hipSuccess || hipStreamWaitEvent(st, ev_done, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(sx);
+                if (!rc) rc = SINDDM_E_BADARG;
+            }
         }
         i0 += len;
     }
@@ -1578,7 +1601,7 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W) {
     NetPlan p = make_plan(dim);
     if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
     const BlockPlan& b = p.blk[2];                      // the dim -> dim block
-    const int Wp = fwd_pitch(W);
+    const int Wp = fwd_pitch(p, W);
     if (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout)) return 7;
     return conv3x3_path(b.cout, b.cout, b.coblks, B, H, Wp);
 }

@@ -325,6 +325,38 @@ def test_bench_strong_scaling_c4_two_ranks():
     assert fs["images"] == 9 and fs["finite"] and fs["all_gather_seconds"] > 0
 
 
+def test_bench_default_workload_is_the_same_at_every_n():
+    """`bench.py --gpus N` must run ONE workload at every N so that value(N) / value(1) is a speed-up.
+    The default line of one rank and of two ranks (both on the one device, gloo for the collectives) name the same
+    config.workload (C3 at 64 chains per GPU, weak scaling) and differ in n_gpus / global_batch / timings only; the
+    strong-scaling records sit under the same keys at every N."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(SINDDM_BENCH_BACKEND="gloo", SINDDM_BENCH_ONE_DEVICE="1")
+    lines = {}
+    for n in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1",
+                            "--no-cpu", "--no-c2", "--no-train", "--no-full", "--no-ab"] + (["--no-strong"] if n == 2 else []),
+                           capture_output=True, text=True, env=env, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[n] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = lines[1], lines[2]
+    assert a["config"]["workload"] == b["config"]["workload"] and a["config"]["workload"].startswith("C3")
+    assert a["scaling"] == b["scaling"] == "weak" and a["metric"] == b["metric"] and a["unit"] == b["unit"] and a["dtype"] == b["dtype"]
+    assert a["config"]["batch_per_gpu"] == b["config"]["batch_per_gpu"] == 64
+    assert (a["n_gpus"], a["comm_world_size"], a["config"]["global_batch"]) == (1, 1, 64)
+    assert (b["n_gpus"], b["comm_world_size"], b["config"]["global_batch"]) == (2, 2, 128)
+    assert a["config"]["finest_hw"] == b["config"]["finest_hw"] == [411, 512]
+    # N = 1 carries the strong-scaling records under the keys an N > 1 line uses: the FULL global batch on the one GPU
+    assert a["c4_strong"]["global_batch"] == 128 and a["c4_strong"]["n_gpus"] == 1 and a["c4_strong"]["scaling"] == "strong"
+    assert a["c5_strong"]["global_batch"] == 32 and a["c5_strong"]["value"] > 0
+
+
 def test_integration_option_b_snippet():
     """INTEGRATION.md option B, executed as written: the reference-side ctypes stub (extracted from the markdown) wraps
     a network with the reference's parameter order and must reproduce the oracle; plugged into

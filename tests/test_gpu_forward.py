@@ -235,6 +235,30 @@ def test_dims_with_channels_not_multiple_of_4(dim):
         assert rel_l2(p.grad.cpu(), sd[name].grad) < 3e-4, name
 
 
+@pytest.mark.parametrize("dim", [20, 10, 8, 28, 12])
+@pytest.mark.parametrize("B,H,W", [(2, 33, 45), (1, 40, 191), (3, 26, 202)])
+def test_inference_odd_widths_at_dims_off_the_winograd_path(dim, B, H, W):
+    """inference pads its rows to 4 floats only when every 3x3 conv of the plan runs on a kernel that
+    writes the pad columns as zeros.  Dims whose channel counts send a conv to the direct implicit-GEMM kernel (dim / 2 or
+    dim not a multiple of 4, 3 < C_in < 8) must keep plain rows: net.infer and a fused sampler run at W % 4 != 0 --
+    including widths >= 190, where the register-window depthwise kernel would read the pads -- against the oracle."""
+    from sinddm_amd.models import SinDDMNet
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    sd = closed_form_state_dict(dim)
+    net.load_state_dict(sd)
+    x = hash_randn((B, 3, H, W), 700 + dim + W)
+    t = torch.tensor([(61 * (i + 2)) % 1000 for i in range(B)], dtype=torch.long)
+    got = net.infer(x.to(DEV), t.to(DEV), 0, 2.0).cpu()
+    ref = O.net_forward(sd, x, t, 2)
+    assert rel_l2(got, ref) < 1e-5, (dim, W, rel_l2(got, ref))
+    # right edge on its own (a wrong pad column shows up in the last few columns, diluted in the whole-image norm)
+    assert rel_l2(got[..., -4:], ref[..., -4:]) < 2e-5
+    # host-t path of the sampler (one row of conditioning for the batch)
+    g1 = net.infer(x.to(DEV), None, 123, 1.0).cpu()
+    r1 = O.net_forward(sd, x, torch.full((B,), 123, dtype=torch.long), 1)
+    assert rel_l2(g1, r1) < 1e-5 and rel_l2(g1[..., -4:], r1[..., -4:]) < 2e-5
+
+
 @pytest.mark.parametrize("dim,B,H,W", [(160, 1, 12, 20), (160, 2, 47, 61), (160, 4, 94, 126), (160, 16, 48, 64),
                                        (160, 16, 186, 248), (32, 3, 67, 90), (20, 2, 33, 41), (16, 5, 24, 50)])
 def test_forward_and_input_gradient_bit_reproducible(dim, B, H, W):
