@@ -72,8 +72,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--f44", type=int, default=None, choices=(0, 1),
                     help="A/B only: force the F(4x4,3x3) kernel on / off (sinddm_debug_set_f44); default = the library's")
-    ap.add_argument("--h2", type=int, default=None, choices=(0, 1),
-                    help="A/B only: binary16 hi/lo direct 3x3 kernel on / off (sinddm_debug_set_h2); default = on")
+    ap.add_argument("--h2", type=int, default=None, choices=(0, 1, 3),
+                    help="A/B only: binary16 hi/lo 3x3 kernels (sinddm_debug_set_h2): 0 off, 1 direct kernel only, 3 (default) Winograd + direct")
     return ap.parse_args()
 
 
@@ -304,7 +304,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     mix = {}
-    for gen, name in ((7, "conv_h2_kernel"), (6, "conv_wino6_kernel"), (4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"), (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
+    for gen, name in ((8, "conv_wh_kernel"), (7, "conv_h2_kernel"), (6, "conv_wino6_kernel"), (4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"), (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
         g_ms, g_n, _, _ = _prof(lib, 10 + gen, 0)
         if g_n:
             mix[name] = {"launches": int(g_n), "avg_launch_ms": round(g_ms / g_n, 4)}

@@ -38,7 +38,8 @@ int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flop
 int sinddm_debug_conv_path(int dim, int B, int H, int W);
 
 /* The same question for INFERENCE launches (sinddm_net_forward / sinddm_sample_chain: rows padded to 4 floats inside the
- * workspace): 7 = conv_h2 (binary16 hi/lo direct kernel, the default where a launch has >= 2 items of 8x64 pixels per CU),
+ * workspace): 8 = conv_wh (Winograd F(2x4), binary16 hi/lo frequency GEMMs: >= 2 items of 8x32 pixels x 80 channels per CU),
+ * 7 = conv_h2 (binary16 hi/lo direct kernel: >= 2 items of 8x64 pixels per CU),
  * else the value sinddm_debug_conv_path gives for the padded shape. */
 int sinddm_debug_infer_path(int dim, int B, int H, int W);
 
@@ -48,9 +49,10 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W);
  * both kernels in one process. */
 int sinddm_debug_set_f44(int on);
 
-/* Process-global switch of the binary16 hi/lo direct 3x3 kernel (conv_h2.h; 7 from sinddm_debug_conv_path): 0 keeps the
- * launches that qualify on the fp32-MFMA Winograd kernels, != 0 (the default) lets them take it.  Returns the previous value.
- * For A/B measurements and parity tests of both paths in one process; the library itself never changes it. */
+/* Process-global switch of the binary16 hi/lo 3x3 kernels: bit 0 = conv_h2.h (direct implicit GEMM; 7 from
+ * sinddm_debug_infer_path), bit 1 = conv_wh.h (Winograd F(2x4) with binary16 frequency GEMMs; 8, preferred where both
+ * apply).  0 keeps the launches that qualify on the fp32-MFMA Winograd kernels; the default is 3.  Returns the previous value.
+ * For A/B measurements and parity tests of the paths in one process; the library itself never changes it. */
 int sinddm_debug_set_h2(int on);
 
 /* ONE SinDDMConvBlock (l = 0..3 of the plan of SinDDMNet(dim); reference SinDDM/models.py:51-80) forward + backward on

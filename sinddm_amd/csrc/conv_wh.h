@@ -1,0 +1,619 @@
+// Winograd F(2x4,3x3) 3x3 convolution with the 24 frequency GEMMs on the gfx950 BINARY16 matrix pipe, fp32-equivalent:
+// the transformed input V = B^T d B (computed in fp32, as conv_wino4.h does) and the transformed weights U = G g G^T (float64
+// at pack time) are each split into two binary16 pieces (hi = rn16(a), lo = rn16(a - hi); conv_h2.h has the error analysis)
+// and every product runs as ALL FOUR terms hi*hi + hi*lo + lo*hi + lo*lo with fp32 accumulation inside
+// v_mfma_f32_16x16x32_f16: K = 32 = 16 input channels x {hi, lo} of V, against [U_hi | U_hi] and [U_lo | U_lo].
+//
+// Why (round 5): the direct binary16 kernel (conv_h2.h) executes 3 x 9 = 27 binary16 MACs per (pixel, ci, co) and sits on the
+// socket's power limit at the SAME energy per launch as the fp32 Winograd kernel (profiles/r05b_h2_power.txt: the binary16
+// pipe costs ~1/9 of the fp32 pipe's energy per FLOP and the direct form needs 9x the FLOPs of F(2x4) fp32).  The lever is the
+// multiply count: F(2x4) in binary16 is 4 x 3 = 12 MACs per (pixel, ci, co).
+//
+// Work item = 8x32 pixels (32 tiles of 2x4: tile row tr 0..3, tile column tc 0..7) x 80 output channels.  One persistent
+// workgroup of 8 waves (two per SIMD) per CU.  Per 16-channel chunk:
+//   * raw halo tile (16 x 10 x 34 fp32) global -> LDS by buffer_load ... lds (out-of-image = out-of-range offset = zeros),
+//     double buffered, two chunks ahead;
+//   * T phase (the two service waves): task = (tile, channel pair, half of the vertical frequencies): 2-D input transform as
+//     packed fp32 on the channel pair, x 2^s (per-sample scale from the tensor's running max), split, written to LDS as the A
+//     fragments of the 24 frequency GEMMs: [f][tile group of 16][k group: piece x channel half][tile][8 x f16] (48 KB, double buffered);
+//   * M phase (waves 0..5): wave w owns frequencies 4w .. 4w+3 of all 32 tiles x 80 channels (4 x 2 x 5 accumulator tiles =
+//     160 registers); its U fragments come straight from L2 into registers one frequency (5 column tiles) ahead.
+//   One barrier per chunk.
+// Epilogue: per 16-channel column tile the waves exchange their frequencies through LDS ([f][co][tile], the V buffers);
+// thread = (tile, channel) gathers 24 values, inverse transform A^T M A, scale, bias, GELU / GELU' / residual, 16-byte stores.
+//
+// Replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] / nn.Conv2d(dim_out, dim_out, 3, padding=1) [+ residual] of
+// SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80) for inference launches with enough items per CU.
+#pragma once
+#include <utility>
+#include "conv_h2.h"
+
+namespace sinddm {
+
+// compile-time loop (a loop over the accumulator array that the unroller gives up on turns the array into scratch memory)
+template <class F, int... I>
+__device__ __forceinline__ void wh_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void wh_static_for(F&& f) {
+    wh_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Compile-time timing ablations (-DWH_ABL=bits; results are WRONG, never ship):
+//   1 no raw-tile requests   2 no input transform   4 U fragments loaded once per item   8 no MFMAs   16 no epilogue loads / stores
+#ifndef WH_ABL
+#define WH_ABL 0
+#endif
+#ifdef WH_TIMING
+// s_memtime stamps of every workgroup's third item (debug builds only; tools/wh_seg.py): [launch % 8][workgroup][wave][32]
+__device__ unsigned long long g_wh_seg[8 * 256 * 8 * 32];
+#define WH_SEG(slot) do { if (j == 2) g_wh_seg[((p.mtp * 256 + blockIdx.x) * 8 + wv) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WH_SEG(slot) do {} while (0)
+#endif
+constexpr int WH_TH = 8, WH_TW = 32;
+constexpr int WH_RS = 40;                      // LDS row stride of the raw tile: image columns x0-4 .. x0+35 (ten aligned 16-byte groups)
+constexpr int WH_PS = 408;                     // plane stride (floats): 10 x 40 + 8 (4 PS = 32 (mod 64): the two channel quads of a lane pair hit disjoint banks)
+constexpr int WH_RAW = 16 * WH_PS * 4;         // bytes of one raw buffer: 26 112
+constexpr int WH_V = 24 * 2 * 64 * 16;         // bytes of one V buffer: 49 152
+constexpr int WH_XS = 36;                      // tile stride of the epilogue's exchange rows (32 + 4: conflict-free 16-byte writes)
+constexpr int WH_X = 24 * 16 * WH_XS * 4;      // one exchange buffer [f][co][tile]: 55 296
+constexpr int WH_DUMMY = 2 * WH_RAW + 2 * WH_X; // 256 bytes per service wave: landing area of the L2-warming requests
+constexpr int WH_LDS = WH_DUMMY + 512;         // 163 328 (the V buffers are the first 98 304 bytes behind the raw buffers)
+static_assert(2 * WH_X >= 2 * WH_V && WH_LDS <= 160 * 1024, "LDS of a gfx950 CU");
+constexpr int WH_TARGET_EXP = 10;              // scaled max |x| in [2^10, 2^11): |V| <= 20 max |x| stays below 65 504
+constexpr int WH_COB = 80;                     // output channels per item
+
+inline bool wh_shape_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout % WH_COB == 0; }
+// f16 elements of the packed image: [co block][chunk][f 24][n 5][piece 2][k half 2][co 16][8]
+inline long long wh_image_halfs(int cin, int cout) { return (long long)(cout / WH_COB) * (cin / 16) * 24 * 5 * 512; }
+
+__device__ __forceinline__ int wh_shift_for(float m, int target) {
+    const unsigned bits = __float_as_uint(m) & 0x7fffffffu;
+    const int e = (int)(bits >> 23);
+    if (e == 0 || e == 255) return 0;
+    int s = target - (e - 127);
+    return s > 100 ? 100 : (s < -100 ? -100 : s);
+}
+
+// U = G2 g G4^T of one (m = output channel, k = input channel) in float64; f = i * 6 + j
+__device__ __forceinline__ void wh_u24(const float* __restrict__ w, long long base, int transpose, double (&u)[24]) {
+    const double G2[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
+    const double G4[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
+                             {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = (double)(transpose ? w[base + (2 - a) * 3 + (2 - b)] : w[base + a * 3 + b]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double r = 0.;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) r += G4[j][b] * g[a][b];
+                acc += G2[i][a] * r;
+            }
+            u[i * 6 + j] = acc;
+        }
+}
+
+// per output channel: 2^-e, e = shift of max |U| over (f, k) to [2^13, 2^14)
+__global__ __launch_bounds__(256) void wh_wscale_kernel(const float* __restrict__ w, float* __restrict__ wsinv, int cin,
+                                                         int cout, int transpose) {
+    const int m = blockIdx.x;
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    float mx = 0.f;
+    if (m < M)
+        for (int k = threadIdx.x; k < K; k += 256) {
+            double u[24];
+            wh_u24(w, transpose ? ((long long)k * cin + m) * 9 : ((long long)m * cin + k) * 9, transpose, u);
+#pragma unroll
+            for (int f = 0; f < 24; ++f) mx = fmaxf(mx, fabsf((float)u[f]));
+        }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0 && m < M) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        wsinv[m] = h2_pow2(-h2_shift_for(mx));
+    }
+}
+
+// one thread per (co block, chunk, n, k half, co16, e) -> its 24 frequencies x 2 pieces
+__global__ __launch_bounds__(256) void wh_pack_kernel(const float* __restrict__ w, const float* __restrict__ wsinv,
+                                                       _Float16* __restrict__ img, int cin, int cout, int transpose,
+                                                       long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    const int nch = K / 16;
+    long long r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int co16 = (int)(r % 16); r /= 16;
+    const int kh = (int)(r % 2); r /= 2;
+    const int n = (int)(r % 5); r /= 5;
+    const int ch = (int)(r % nch); r /= nch;
+    const int cb = (int)r;
+    const int m = cb * WH_COB + n * 16 + co16;
+    const int k = ch * 16 + kh * 8 + e;
+    double u[24];
+    if (m < M && k < K) wh_u24(w, transpose ? ((long long)k * cin + m) * 9 : ((long long)m * cin + k) * 9, transpose, u);
+    else {
+#pragma unroll
+        for (int f = 0; f < 24; ++f) u[f] = 0.;
+    }
+    const double sc = m < M ? 1.0 / (double)wsinv[m] : 1.0;
+#pragma unroll
+    for (int f = 0; f < 24; ++f) {
+        const float s = (float)(u[f] * sc);                       // (rounded once to fp32: what an fp32 kernel would hold)
+        const _Float16 hi = (_Float16)s;
+        const _Float16 lo = (_Float16)(s - (float)hi);
+        const long long o = ((((long long)(cb * nch + ch) * 24 + f) * 5 + n) * 2) * 256 + (kh * 16 + co16) * 8 + e;
+        img[o] = hi;
+        img[o + 256] = lo;
+    }
+}
+
+inline int wh_pack_launch(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st) {
+    const int M = transpose ? cin : cout, K = transpose ? cout : cin;
+    hipLaunchKernelGGL(wh_wscale_kernel, dim3(M), dim3(256), 0, st, w, wsinv, cin, cout, transpose);
+    SINDDM_LAUNCH_CHECK();
+    const long long total = (long long)(M / WH_COB) * (K / 16) * 5 * 2 * 16 * 8;
+    hipLaunchKernelGGL(wh_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, wsinv,
+                       static_cast<_Float16*>(img), cin, cout, transpose, total);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Workgroup barrier that publishes LDS only.  __syncthreads() also drains vmcnt: in this kernel that would wait out the U
+// fragments in flight for the next chunk at every chunk barrier, and the output stores of the previous pass at every epilogue
+// barrier (measured: 4 300 cycles per epilogue pass, tools/wh_seg.py).  The LDS-DMA of the service waves is published by
+// their own s_waitcnt vmcnt in front of the barrier.
+__device__ __forceinline__ void wh_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- the kernel ------------------------------------------------------------------------------------------------
+// Roles: waves 0..5 multiply (frequencies 4w .. 4w+3), waves 6 and 7 are the service waves: they request the raw tiles
+// (HBM-latency LDS-DMA) and run the input transform.  Vector memory returns in order per wave, so a wave that waits for U
+// fragments out of L2 must not have tile requests in its queue: with the DMA in the multiplying waves every U refill
+// queued behind a tile request waited out the HBM round trip (first version: 12 700 cycles per chunk instead of ~2 500).
+__global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_xcd, int wg_per_xcd) {
+    typedef __attribute__((address_space(3))) float lds_f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const sbytes = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* const sRaw = sbytes;
+    unsigned char* const sV = sbytes + 2 * WH_RAW;
+    const unsigned lds0 = (unsigned)(size_t)(lds_f*)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int H = p.H, W = p.W;
+    const int HW = H * W;
+    const int Wt = p.Wt > 0 ? p.Wt : W;
+    const int nch = p.nch3;                                  // 16-channel chunks
+    constexpr int OOB = 0x40000000;
+    const bool service_rt = wv >= 6;                         // (two separate instantiations of the item loop below: nothing of one role is live in the other)
+    const int sv = wv - 6;                                   // service wave 0 / 1
+
+    // T-phase role of a service thread: wave sv transforms the channels it staged itself (8 sv .. 8 sv + 7: no other wave's
+    // requests are involved); lane -> (channel quad q = lane & 1, tile (lane >> 1) & 15 of tile group mg = lane >> 5), task =
+    // half of the vertical frequencies.  Consecutive lanes write consecutive 8 bytes of a V fragment.
+    const int t_q = lane & 1, t_t16 = (lane >> 1) & 15, t_mg = lane >> 5;
+    const int t_tr = t_mg * 2 + (t_t16 >> 3), t_tc = t_t16 & 7;
+    const int t_rd0 = (((sv & 1) * 8 + 4 * t_q) * WH_PS + 2 * t_tr * WH_RS + 4 * t_tc) * 4;   // + plane k + (hs + rr) rows; columns +3, +4..7, +8
+    const int t_wr0 = ((t_mg * 64 + (sv & 1) * 16 + t_t16) * 16) + t_q * 8;                  // + hs * 12 * 2048 + (ii * 6 + j) * 2048 + piece * 512
+    // M-phase role: frequencies 4 wv + (0..3).  V fragment of (f, mg, piece): lane (tile l16, k group kq) reads the 16 bytes of
+    // channel half kq & 1 -- the same bytes for kq and kq + 2 (LDS broadcast): K = 32 = [V | V] against [U_hi | U_lo]
+    const int f0 = 4 * (service_rt ? 0 : wv);
+    const int a_rd = ((kq & 1) * 16 + l16) * 16;
+
+    // persistent: XCD `xcd` owns a contiguous range of tiles; workgroup `ls` of the XCD takes tiles ls, ls + wg_per_xcd, ... and runs
+    // the co blocks of a tile back to back (the second pass over the raw tile finds it in L2)
+    const int xcd = blockIdx.x & 7, ls = blockIdx.x >> 3;
+    const int tpi = p.tilesX * p.tilesY;
+    (void)items_per_xcd;
+    struct Item { int b, y0, x0, cb; bool ok; };
+    auto decode = [&](int j) {
+        Item it;
+        const int q = j / p.coblks;
+        it.cb = j - q * p.coblks;
+        const int tl = ls + q * wg_per_xcd;
+        const int tile = xcd * p.tiles_per_xcd + tl;
+        it.ok = tl < p.tiles_per_xcd && tile < p.ntiles;
+        const int tcl = it.ok ? tile : 0;
+        it.b = tcl / tpi;
+        const int trm = tcl - it.b * tpi;
+        const int tyi = trm / p.tilesX;
+        it.y0 = tyi * WH_TH;
+        it.x0 = (trm - tyi * p.tilesX) * WH_TW;
+        return it;
+    };
+    // raw staging (service waves): wave sv loads channels 8 sv .. 8 sv + 7 of the chunk, 100 aligned 16-byte groups per plane =
+    // two loads per channel (lanes 0..63, then lanes 0..35; out of the image = out-of-range offset = zeros), into 64 REGISTERS,
+    // and writes them to LDS one iteration later.  (LDS-DMA was tried first: an LDS-DMA instruction costs the issuing wave
+    // 150-400 cycles whatever its size, the instructions in flight are few, and its traffic halved the rate of the U loads of the
+    // multiplying waves -- tools/wh_seg.py: 3 600 - 7 000 cycles per chunk.  The service waves own 200 idle registers: those are
+    // the look-ahead buffer, and only the wave that loaded a plane reads it, so no other wave waits on these loads.)
+    auto stage_offsets = [&](const Item& it, int (&vo)[2]) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int qd = ps * 64 + lane;
+            const int r = qd / 10, g = qd - r * 10;
+            const int gy = it.y0 - 1 + r, gx = it.x0 - 4 + 4 * g;
+            vo[ps] = (qd < 100 && gy >= 0 && gy < H && gx >= 0 && gx < W) ? (gy * W + gx) * 4 : OOB;
+        }
+    };
+    auto role_body = [&](auto ROLE) {
+    constexpr bool service = decltype(ROLE)::value;
+    f32x4 stg[16];
+    auto stage_load = [&](const __amdgpu_buffer_rsrc_t& rs, const int (&vo)[2], int c) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int so = (c * 16 + (sv & 1) * 8 + k) * HW * 4;
+            stg[2 * k] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[0], so, 0));
+            stg[2 * k + 1] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[1], so, 0));
+        }
+    };
+    auto stage_write = [&](unsigned char* raw) {
+        unsigned char* dst = raw + (sv & 1) * 8 * WH_PS * 4 + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            *reinterpret_cast<f32x4*>(dst + k * WH_PS * 4) = stg[2 * k];
+            if (lane < 36) *reinterpret_cast<f32x4*>(dst + k * WH_PS * 4 + 1024) = stg[2 * k + 1];
+        }
+    };
+    auto in_rsrc = [&](int b) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)b * p.Cin * HW), 0, p.Cin * HW * 4, 0x00020000);
+    };
+
+    Item cur = decode(0);
+    if (!cur.ok) return;
+    int svoff[2] = {OOB, OOB};
+    if constexpr (service) {                                 // the first item's first chunk
+        stage_offsets(cur, svoff);
+        stage_load(in_rsrc(cur.b), svoff, 0);
+    }
+    for (int j = 0;; ++j) {
+        const Item nxt = decode(j + 1);
+        const int cb = cur.cb, b = cur.b, y0 = cur.y0, x0 = cur.x0;
+
+        const int xs = p.amax_in ? wh_shift_for(p.amax_in[(size_t)b * AMAX_STRIDE], WH_TARGET_EXP) : 0;
+        const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
+        const f32x2 sx2{sx, sx};
+
+        const __amdgpu_buffer_rsrc_t rsin = in_rsrc(b);
+
+        // ---- T phase of one chunk (service waves): raw buffer -> V buffer ----
+        auto transform = [&](const unsigned char* raw, unsigned char* vb) {
+            if (WH_ABL & 2) return;
+            wh_static_for<2>([&](auto HS) {
+                constexpr int hs = decltype(HS)::value;
+                const unsigned char* rp = raw + t_rd0 + hs * WH_RS * 4;
+                unsigned char* wp = vb + t_wr0 + hs * (12 * 2048);
+                // rows r0 .. r0+2 (r0 = 2 tr + hs) of the patch, its columns = LDS columns 4 tc + 3 .. + 8, four channels as two
+                // packed pairs
+                f32x2 d[2][3][6];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        const unsigned char* r0 = rp + (2 * pr) * WH_PS * 4 + rr * WH_RS * 4;
+                        const unsigned char* r1 = r0 + WH_PS * 4;
+                        const float a3 = *reinterpret_cast<const float*>(r0 + 12), b3 = *reinterpret_cast<const float*>(r1 + 12);
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(r0 + 16), b4 = *reinterpret_cast<const f32x4*>(r1 + 16);
+                        const float a8 = *reinterpret_cast<const float*>(r0 + 32), b8 = *reinterpret_cast<const float*>(r1 + 32);
+                        d[pr][rr][0] = f32x2{a3, b3};
+                        d[pr][rr][1] = f32x2{a4[0], b4[0]}; d[pr][rr][2] = f32x2{a4[1], b4[1]};
+                        d[pr][rr][3] = f32x2{a4[2], b4[2]}; d[pr][rr][4] = f32x2{a4[3], b4[3]};
+                        d[pr][rr][5] = f32x2{a8, b8};
+                    }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    // vertical B^T (F(2,3)): i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; this task's rows start at hs
+                    //   hs = 0: i = 0 -> d[0] - d[2];  i = 1 -> d[1] + d[2]        hs = 1: i = 2 -> d[1] - d[0];  i = 3 -> d[0] - d[2]
+                    h16x2 hi[2][6], lo[2][6];
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        f32x2 r[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            if (ii == 0) r[c] = hs == 0 ? d[pr][0][c] - d[pr][2][c] : d[pr][1][c] - d[pr][0][c];
+                            else r[c] = hs == 0 ? d[pr][1][c] + d[pr][2][c] : d[pr][0][c] - d[pr][2][c];
+                        }
+                        // horizontal B^T (F(4,3)): [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+                        const f32x2 s24 = r[4] - 4.f * r[2], s13 = r[3] - 4.f * r[1];
+                        const f32x2 u24 = r[4] - r[2], d31 = r[3] - r[1];
+                        f32x2 v[6];
+                        v[0] = 4.f * r[0] + (r[4] - 5.f * r[2]);
+                        v[1] = s24 + s13;
+                        v[2] = s24 - s13;
+                        v[3] = u24 + 2.f * d31;
+                        v[4] = u24 - 2.f * d31;
+                        v[5] = 4.f * r[1] + (r[5] - 5.f * r[3]);
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) {
+                            const f32x2 sc = v[j] * sx2;
+                            hi[pr][j] = __builtin_convertvector(sc, h16x2);
+                            const f32x2 rem = sc - __builtin_convertvector(hi[pr][j], f32x2);
+                            lo[pr][j] = __builtin_convertvector(rem, h16x2);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
+                        *reinterpret_cast<h16x4*>(wp + (ii * 6 + j) * 2048) = h16x4{hi[0][j][0], hi[0][j][1], hi[1][j][0], hi[1][j][1]};
+                        *reinterpret_cast<h16x4*>(wp + (ii * 6 + j) * 2048 + 512) = h16x4{lo[0][j][0], lo[0][j][1], lo[1][j][0], lo[1][j][1]};
+                    }
+                }
+            });
+        };
+
+        // ---- M phase (waves 0..5) ----
+        // (zeroed for every wave: left undefined on the service path the array would be live around the item loop)
+        f32x4 acc[4][2][5];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int n = 0; n < 5; ++n) acc[a][g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // U fragment of (f, n): lane (co = l16, k group kq) = piece kq >> 1 of U[ci = 8 (kq & 1) + 0..7][co]: ONE lane-linear 1 KB
+        // load per fragment, every byte distinct (the first version loaded [U_hi | U_hi] and [U_lo | U_lo]: two 1 KB requests of
+        // which half the lanes were duplicates, and the vector-memory path of the CU, 64 bytes per clock, was the bound)
+        const __amdgpu_buffer_rsrc_t rsw =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w3), 0, 0x7FFFFFF0, 0x00020000);
+        const int wlane = lane * 16;
+        const int wbase = ((cb * nch) * 24 + f0) * 5 * 1024;            // + c * 24 * 5120 + (fi * 5 + n) * 1024
+        h16x8 ur[10];                                                    // ring: two frequencies (10 column tiles) ahead
+        auto load_u = [&](int c, int fi, int n, int slot) {
+            const int so = wbase + (c * 24 * 5 + fi * 5 + n) * 1024;
+            ur[slot] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, so, 0));
+        };
+        auto multiply = [&](int c, const unsigned char* vb) {
+            const unsigned char* A = vb + f0 * 2048 + a_rd;
+            wh_static_for<4>([&](auto FI) {
+                constexpr int fi = decltype(FI)::value;
+                const h16x8 ah0 = *reinterpret_cast<const h16x8*>(A + fi * 2048);
+                const h16x8 ah1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024);
+                const h16x8 al0 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 512);
+                const h16x8 al1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024 + 512);
+                wh_static_for<5>([&](auto NN) {
+                    constexpr int n = decltype(NN)::value;
+                    constexpr int slot = (fi & 1) * 5 + n;
+                    const h16x8 u = ur[slot];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (WH_ABL & 8) {
+                        asm volatile("" ::"v"(ah0), "v"(ah1), "v"(al0), "v"(al1), "v"(u));
+                    } else {
+                        acc[fi][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, u, acc[fi][0][n], 0, 0, 0);
+                        acc[fi][1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, u, acc[fi][1][n], 0, 0, 0);
+                        acc[fi][0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, u, acc[fi][0][n], 0, 0, 0);
+                        acc[fi][1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, u, acc[fi][1][n], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (the slot is free: refill it with the same column tile two frequencies on.  Pinned behind the MFMAs that
+                    // read it -- left to the scheduler all loads of a chunk are hoisted to its top.  Behind the last chunk the
+                    // refill re-reads the last chunk's fragments: no branch, the values are not used)
+                    if (!(WH_ABL & 4)) {
+                        if (fi < 2) load_u(c, fi + 2, n, slot);
+                        else load_u(c + 1 < nch ? c + 1 : c, fi - 2, n, slot);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        };
+
+        // the epilogue's operands of all five passes are requested up front (one exposed round trip per item, not five); thread =
+        // (tile t = tid & 31, co16 = tid >> 5)
+        const int e_t = tid & 31, e_co = tid >> 5;
+        const int e_tr = e_t >> 3, e_tc = e_t & 7;
+        const int ey = y0 + 2 * e_tr, ex = x0 + 4 * e_tc;
+        f32x4 rsd[5][2];
+        float ek[5], ebv[5];
+        auto ep_operands = [&]() {
+            const bool e_in = ex < W;
+#pragma unroll
+            for (int n = 0; n < 5; ++n) {
+                const int co = cb * WH_COB + n * 16 + e_co;
+                ek[n] = inv_sx * p.wsinv[co];
+                ebv[n] = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp) {
+                    rsd[n][pp] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (p.resid && !(WH_ABL & 16) && e_in && ey + pp < H)
+                        rsd[n][pp] = *reinterpret_cast<const f32x4*>(p.resid + ((size_t)b * p.Cout + co) * HW + (size_t)(ey + pp) * W + ex);
+                }
+            }
+        };
+
+        // ---- the two roles run their own loops (same number of barriers): nothing of the one is live in the other ----
+        WH_SEG(0);
+        if constexpr (service) {
+            // the registers hold this wave's planes of chunk 0 (loaded during the previous item's epilogue or in front of the
+            // loop): to LDS, chunk 1 on its way, V(0)
+            stage_write(sRaw);
+            if (nch > 1) stage_load(rsin, svoff, 1);
+            WH_SEG(1);
+            transform(sRaw, sV);
+            wh_barrier();
+            WH_SEG(2);
+            for (int c = 0; c < nch; ++c) {
+                // chunk c + 1 (loaded one iteration ago) goes to LDS -- the one raw buffer: only this wave reads these planes, and
+                // it has finished T(c) --, chunk c + 2 is requested, chunk c + 1 transformed while the others multiply chunk c
+                if (c + 1 < nch) {
+                    stage_write(sRaw);
+                    if (c + 2 < nch) stage_load(rsin, svoff, c + 2);
+                    if (c == 3) WH_SEG(24);
+                    transform(sRaw, sV + ((c + 1) & 1) * WH_V);
+                    if (c == 3) WH_SEG(25);
+                }
+                wh_barrier();
+                if (c < 12) WH_SEG(3 + c);
+            }
+            ep_operands();
+            // the next item's first chunk travels during this item's epilogue
+            if (nxt.ok) {
+                stage_offsets(nxt, svoff);
+                stage_load(in_rsrc(nxt.b), svoff, 0);
+            }
+        } else {
+            wh_static_for<10>([&](auto SL) {
+                constexpr int sl = decltype(SL)::value;
+                load_u(0, sl / 5, sl % 5, sl);
+            });
+            WH_SEG(1);
+            wh_barrier();
+            WH_SEG(2);
+            for (int c = 0; c < nch; ++c) {
+                multiply(c, sV + (c & 1) * WH_V);
+                if (c == 3) WH_SEG(25);
+                wh_barrier();
+                if (c < 12) WH_SEG(3 + c);
+            }
+            ep_operands();
+        }
+        WH_SEG(16);
+
+        // ---- epilogue: per column tile n the multiplying waves hand their frequencies over through LDS (the V buffers) ----
+        // writer: acc[fi][mg][n] = D[tile = mg*16 + 4 kq + r][co = l16]  ->  X[f][co][tile]
+        // reader: thread = (tile t = tid & 31, co16 = tid >> 5)
+        const int e_wr = ((f0 * 16 + l16) * WH_XS + 4 * kq) * 4;    // X[f][co][tile (stride 36)] byte offsets: writer (f0, co = l16, tile 4 kq)
+        const int e_rd = (e_co * WH_XS + e_t) * 4;                  // reader (f = 0, co16, tile)
+        float amax = 0.f;
+        WH_SEG(17);
+        wh_static_for<5>([&](auto NN) {
+            constexpr int n = decltype(NN)::value;
+            unsigned char* X = sV + (n & 1) * WH_X;
+            if constexpr (!service) {
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        *reinterpret_cast<f32x4*>(X + e_wr + fi * (16 * WH_XS * 4) + g * 64) = acc[fi][g][n];
+            }
+            wh_barrier();
+            WH_SEG(18 + n);
+            float m[24];
+#pragma unroll
+            for (int f = 0; f < 24; ++f) m[f] = *reinterpret_cast<const float*>(X + e_rd + f * (16 * WH_XS * 4));
+            // vertical A^T (F(2,3)): y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
+            float q[2][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                q[0][j] = m[j] + m[6 + j] + m[12 + j];
+                q[1][j] = m[6 + j] - m[12 + j] - m[18 + j];
+            }
+            const int co = cb * WH_COB + n * 16 + e_co;
+            const float k = ek[n];
+            const float bv = ebv[n];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                // horizontal A^T (F(4,3)): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+                const float* z = q[pp];
+                const float s12 = z[1] + z[2], d12 = z[1] - z[2], s34 = z[3] + z[4], d34 = z[3] - z[4];
+                f32x4 v{z[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + z[5]};
+                const int y = ey + pp;
+                if ((WH_ABL & 16) && v[0] != 123.456f) continue;
+                if (y < H && ex < W) {
+                    const size_t o = ((size_t)b * p.Cout + co) * HW + (size_t)y * W + ex;
+                    v = v * k + bv;
+                    if (p.out_pre) *reinterpret_cast<f32x4*>(p.out_pre + o) = v;
+                    if (p.act == 1) v = gelu_erf4(v);
+                    else if (p.act == 2) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(a[e]);
+                    }
+                    v += rsd[n][pp];
+                    if (ex + 4 > Wt) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ex + e < Wt ? v[e] : 0.0f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[e]));
+                    *reinterpret_cast<f32x4*>(p.out + o) = v;
+                }
+            }
+        });
+        if (p.amax_out) amax_publish(amax, p.amax_out + (size_t)b * AMAX_STRIDE);
+        wh_barrier();                                     // (the next item's T(0) writes the V buffers)
+        WH_SEG(23);
+        if (!nxt.ok) break;
+        cur = nxt;
+    }
+    };
+    if (service_rt) role_body(std::true_type{});
+    else role_body(std::false_type{});
+}
+
+#ifndef SINDDM_WH_MIN_ITEMS_PER_CU
+#define SINDDM_WH_MIN_ITEMS_PER_CU 2
+#endif
+#ifndef SINDDM_CONV_WH
+#define SINDDM_CONV_WH 1
+#endif
+// Run-time switch (process-global, sinddm_debug_set_h2 bit 1): 0 = the launches stay on conv_h2 / the fp32 kernels
+inline int& conv_wh_flag() {
+    static int on = 1;
+    return on;
+}
+
+inline bool conv_wh_applies(int B, int H, int W, int cin, int cout) {
+    if (!SINDDM_CONV_WH || !conv_wh_flag() || !wh_shape_ok(cin, cout) || W % 4 != 0) return false;
+    if ((long long)cin * H * W * 4 >= 0x40000000LL) return false;      // (one sample's input is addressed as a 32-bit buffer)
+    return (long long)B * ((W + WH_TW - 1) / WH_TW) * ((H + WH_TH - 1) / WH_TH) * (cout / WH_COB) >=
+           (long long)SINDDM_WH_MIN_ITEMS_PER_CU * wino2_cu_count();
+}
+
+inline int conv_wh_launch(const ConvArgs& a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    if (!wh_shape_ok(a.Cin, a.Cout) || a.W % 4 != 0 || !a.wsinv || (long long)a.Cin * a.H * a.W * 4 >= 0x40000000LL)
+        return SINDDM_E_BADSHAPE;
+    ConvProfiler& prof = conv_profiler();
+    const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
+    if (rec) {
+        while (prof.created <= prof.used) {
+            (void)hipEventCreate(&prof.ev[2 * prof.created]);
+            (void)hipEventCreate(&prof.ev[2 * prof.created + 1]);
+            ++prof.created;
+        }
+        (void)hipEventRecord(prof.ev[2 * prof.used], st);
+    }
+    a.nch3 = a.Cin / 16;
+    a.coblks = a.Cout / WH_COB;
+    a.tilesX = (a.W + WH_TW - 1) / WH_TW;
+    a.tilesY = (a.H + WH_TH - 1) / WH_TH;
+    a.ntiles = a.B * a.tilesX * a.tilesY;
+    a.tiles_per_xcd = (a.ntiles + 7) / 8;
+    const int ipx = a.tiles_per_xcd * a.coblks;
+    int wpx = wino2_cu_count() / 8;
+    if (wpx < 1) wpx = 1;
+    if (wpx > ipx) wpx = ipx;
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wh_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, WH_LDS);
+    if (attr_rc != hipSuccess) return (int)attr_rc;
+#ifdef WH_TIMING
+    static int wh_launch_no = 0;
+    a.mtp = wh_launch_no++ % 8;                  // (the kernel does not read mtp otherwise: stamp row of this launch)
+#endif
+    hipLaunchKernelGGL(conv_wh_kernel, dim3(wpx * 8), dim3(512), WH_LDS, st, a, ipx, wpx);
+    if (rec) {
+        (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
+        const double fl = 2.0 * a.B * a.H * (a.Wt > 0 ? a.Wt : a.W) * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
+        // executed: four binary16 MFMA terms x 24 frequencies per 8 outputs, on whole 8x32 items
+        prof.note(1, fl, 2.0 * a.ntiles * 32.0 * 24.0 * 4.0 * (double)a.Cout * a.Cin, 8);
+    }
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace sinddm

@@ -24,6 +24,10 @@ inline bool h2_shape_ok(int cin, int cout) {
     return cin >= 16 && cin % 16 == 0 && (nt == 3 || nt == 5);
 }
 
+// conv_wh.h (Winograd F(2x4) with binary16 hi/lo frequency GEMMs): packed image [co block of 80][chunk of 16 ci][f 24][n 5][piece][k half][co 16][8 x f16]
+inline bool wh_plan_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout % 80 == 0; }
+inline long long wh_plan_halfs(int cin, int cout) { return (long long)(cout / 80) * (cin / 16) * 24 * 5 * 512; }
+
 struct BlockPlan {
     int cin, cout;
     // flat parameter offsets (floats)
@@ -46,6 +50,8 @@ struct BlockPlan {
     int64_t pk_w1g, pk_w2g;
     // conv_h2.h images (float offsets; 16-byte aligned) and their per-output-channel 2^-e arrays; -1 = shape not supported
     int64_t pk_h1, pk_h2, pk_hs1, pk_hs2;
+    // conv_wh.h images and their per-output-channel 2^-e arrays; -1 = shape not supported
+    int64_t pk_q1, pk_q2, pk_qs1, pk_qs2;
     int cond_off;  // offset of this block's per-sample bias inside the cond vector
 };
 
@@ -131,6 +137,14 @@ inline NetPlan make_plan(int dim) {
             b.pk_h2 = q; q += h2_image_halfs(b.cout, h2_nt_for(b.cout)) / 2;
             b.pk_hs2 = q; q += h2_nt_for(b.cout) * 32;
         } else b.pk_h2 = b.pk_hs2 = -1;
+        if (wh_plan_ok(b.cin, b.cout)) {
+            b.pk_q1 = q; q += wh_plan_halfs(b.cin, b.cout) / 2;
+            b.pk_qs1 = q; q += (b.cout + 63) / 64 * 64;
+        } else b.pk_q1 = b.pk_qs1 = -1;
+        if (wh_plan_ok(b.cout, b.cout)) {
+            b.pk_q2 = q; q += wh_plan_halfs(b.cout, b.cout) / 2;
+            b.pk_qs2 = q; q += (b.cout + 63) / 64 * 64;
+        } else b.pk_q2 = b.pk_qs2 = -1;
         b.cond_off = coff;
         coff += b.cin;
     }

@@ -4,6 +4,7 @@
 #include "conv_wino.h"
 #include "conv_wino4.h"
 #include "conv_h2.h"
+#include "conv_wh.h"
 #include "internal.h"
 #if SINDDM_WINO_F44_BUILD
 #include "conv_wino6.h"
@@ -277,6 +278,14 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
         }
         if (b.pk_h2 >= 0) {
             rc = h2_pack_launch(params + b.c2_w, packed + b.pk_hs2, packed + b.pk_h2, b.cout, b.cout, 0, st);
+            if (rc) return rc;
+        }
+        if (b.pk_q1 >= 0) {
+            rc = wh_pack_launch(params + b.c1_w, packed + b.pk_qs1, packed + b.pk_q1, b.cin, b.cout, 0, st);
+            if (rc) return rc;
+        }
+        if (b.pk_q2 >= 0) {
+            rc = wh_pack_launch(params + b.c2_w, packed + b.pk_qs2, packed + b.pk_q2, b.cout, b.cout, 0, st);
             if (rc) return rc;
         }
     }
@@ -1105,8 +1114,11 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     const BlockPlan& b = P.blk[l];
     // binary16 hi/lo direct kernel (conv_h2.h): inference launches with a few 8x64 items per CU; `amax` = this block's two
     // running-max scalars (input of conv1, input of conv2), maintained by the kernels that produce those tensors
-    const bool h2a = amax && b.pk_h1 >= 0 && conv_h2_applies(B, H, W, b.cin, b.cout);
-    const bool h2b = amax && b.pk_h2 >= 0 && conv_h2_applies(B, H, W, b.cout, b.cout);
+    // ... or, first choice, the Winograd F(2x4) kernel with binary16 hi/lo frequency GEMMs (conv_wh.h)
+    const bool wha = amax && b.pk_q1 >= 0 && conv_wh_applies(B, H, W, b.cin, b.cout);
+    const bool whb = amax && b.pk_q2 >= 0 && conv_wh_applies(B, H, W, b.cout, b.cout);
+    const bool h2a = wha || (amax && b.pk_h1 >= 0 && conv_h2_applies(B, H, W, b.cin, b.cout));
+    const bool h2b = whb || (amax && b.pk_h2 >= 0 && conv_h2_applies(B, H, W, b.cout, b.cout));
     int rc = Wt > 0 ? dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
                                     Wt, st, W, W, h2a ? amax : nullptr)
                     : dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
@@ -1127,7 +1139,11 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     // ... and, where the image exists and the row pitch allows, its F(4x4) successor (a quarter of the MFMAs gone)
     const bool v6a = v4 && b.pk_w1g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cin);
     const bool v6b = v4 && b.pk_w2g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cout);
-    if (h2a) {
+    if (wha) {
+        c1.w3 = packed + b.pk_q1; c1.wsinv = packed + b.pk_qs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
+        c1.bias = params + b.c1_b;
+        rc = conv_wh_launch(c1, st);
+    } else if (h2a) {
         c1.w3 = packed + b.pk_h1; c1.wsinv = packed + b.pk_hs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
         c1.bias = params + b.c1_b;
         rc = conv_h2_launch(c1, st);
@@ -1173,7 +1189,10 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
             c2.resid = cur; c2.bias = packed + b.pk_b2;
         }
         c2.nch1 = 0;
-        if (h2b) {
+        if (whb) {
+            c2.w3 = packed + b.pk_q2; c2.wsinv = packed + b.pk_qs2; c2.amax_in = amax + 1;
+            rc = conv_wh_launch(c2, st);
+        } else if (h2b) {
             c2.w3 = packed + b.pk_h2; c2.wsinv = packed + b.pk_hs2; c2.amax_in = amax + 1;
             rc = conv_h2_launch(c2, st);
         } else if (v6b) {
@@ -1558,6 +1577,11 @@ int sinddm_debug_w2_phase(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w2_phase), sizeof(unsigned long long) * n);
 }
 #endif
+#ifdef WH_TIMING
+int sinddm_debug_wh_seg(unsigned long long* host_dst, int n) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_wh_seg), sizeof(unsigned long long) * n);
+}
+#endif
 #ifdef W4_TIMING
 int sinddm_debug_w4_seg(unsigned long long* host_dst, int n) {
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_w4_seg), sizeof(unsigned long long) * n);
@@ -1602,14 +1626,17 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W) {
     if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
     const BlockPlan& b = p.blk[2];                      // the dim -> dim block
     const int Wp = fwd_pitch(p, W);
+    if (b.pk_q2 >= 0 && conv_wh_applies(B, H, Wp, b.cout, b.cout)) return 8;
     if (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout)) return 7;
     return conv3x3_path(b.cout, b.cout, b.coblks, B, H, Wp);
 }
 
 int sinddm_debug_set_h2(int on) {
     int& f = conv_h2_flag();
-    const int prev = f;
-    f = on != 0;
+    int& g = conv_wh_flag();
+    const int prev = (f ? 1 : 0) | (g ? 2 : 0);
+    f = (on & 1) != 0;
+    g = (on & 2) != 0;
     return prev;
 }
 

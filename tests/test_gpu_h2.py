@@ -1,6 +1,9 @@
-"""GPU parity of conv_h2.h -- the 3x3 convolutions of inference launches as a direct implicit GEMM on the binary16 matrix
-pipe with every fp32 operand split into two binary16 pieces (three MFMA terms per product, fp32 accumulate, exact
-power-of-two operand scales from the weights' per-channel max and the activation tensor's running max).
+"""GPU parity of the two binary16 hi/lo 3x3 kernels of inference launches:
+  * conv_h2.h -- direct implicit GEMM on the binary16 matrix pipe, every fp32 operand split into two binary16 pieces (three
+    MFMA terms per product, fp32 accumulate, exact power-of-two operand scales from the weights' per-channel max and the
+    activation tensor's per-sample running max)                         (switch 1, sinddm_debug_infer_path = 7)
+  * conv_wh.h -- Winograd F(2x4,3x3) whose 24 frequency GEMMs run on the same pipe with the transformed input and the
+    transformed weights split the same way, all four terms              (switch 3 = the default, path 8)
 
 The gate: the kernel must not be narrower than fp32.  Every evaluation is compared with the FLOAT64
 oracle and its error is held against the error of the fp32 oracle (torch CPU fp32 = the reference's own arithmetic) on the
@@ -42,10 +45,12 @@ def _net_forward_f64(sd, x, t, scale):
     return torch.nn.functional.conv2d(h, sd64["final_conv.0.weight"], sd64["final_conv.0.bias"])
 
 
-@pytest.fixture
-def h2_switch():
+@pytest.fixture(params=[(1, 7), (3, 8)], ids=["h2_direct", "wh_winograd"])
+def h2_switch(request):
     lib = _lib()
-    prev = lib.sinddm_debug_set_h2(1)
+    mode, path = request.param
+    prev = lib.sinddm_debug_set_h2(mode)
+    lib.mode, lib.path = mode, path
     yield lib
     lib.sinddm_debug_set_h2(prev)
 
@@ -56,7 +61,7 @@ def h2_switch():
                                     (24, 94, 126)])     # W % 4 = 2
 def test_error_vs_float64_not_wider_than_fp32(h2_switch, B, H, W):
     lib = h2_switch
-    assert lib.sinddm_debug_infer_path(160, B, H, W) == 7
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == lib.path
     sd = closed_form_state_dict(160)
     net = _net(160, sd)
     x = hash_randn((B, 3, H, W), 1234 + W) * 0.9
@@ -68,11 +73,11 @@ def test_error_vs_float64_not_wider_than_fp32(h2_switch, B, H, W):
     e_h2 = rel_l2(got[idx], ref64)
     e_32 = rel_l2(ref32, ref64)
     lib.sinddm_debug_set_h2(0)
-    assert lib.sinddm_debug_infer_path(160, B, H, W) != 7
+    assert lib.sinddm_debug_infer_path(160, B, H, W) not in (7, 8)
     got_w = net.infer(x.to(DEV), t.to(DEV), 0, 2.0).cpu()
-    lib.sinddm_debug_set_h2(1)
+    lib.sinddm_debug_set_h2(lib.mode)
     e_w = rel_l2(got_w[idx], ref64)
-    print(f"[h2] {B}x{H}x{W}: vs float64  h2 {e_h2:.3e}  fp32-MFMA Winograd {e_w:.3e}  fp32 oracle {e_32:.3e};"
+    print(f"[h2 mode {lib.mode}] {B}x{H}x{W}: vs float64  h2 {e_h2:.3e}  fp32-MFMA Winograd {e_w:.3e}  fp32 oracle {e_32:.3e};"
           f"  h2 vs Winograd {rel_l2(got, got_w):.3e}")
     assert rel_l2(got[idx], ref32) < 1e-5                  # the tolerance every net-forward parity test uses
     assert e_h2 <= 1.5 * e_32, (e_h2, e_32)
@@ -100,7 +105,7 @@ def test_dynamic_range(h2_switch, gain):
     ref64 = _net_forward_f64(sd, x[idx], t[idx], 1)
     ref32 = O.net_forward(sd, x[idx], t[idx], 1)
     e_h2, e_32 = rel_l2(got[idx], ref64), rel_l2(ref32, ref64)
-    print(f"[h2] gain {gain:g}: vs float64  h2 {e_h2:.3e}  fp32 oracle {e_32:.3e}")
+    print(f"[h2 mode {lib.mode}] gain {gain:g}: vs float64  h2 {e_h2:.3e}  fp32 oracle {e_32:.3e}")
     assert torch.isfinite(got).all()
     assert e_h2 <= 1.5 * e_32, (e_h2, e_32)
 
@@ -114,15 +119,15 @@ def test_fused_chain_h2_vs_winograd(h2_switch):
     s = 4
     H, W = d.target_size(s, (1, 1), True, s)
     B = 16
-    assert lib.sinddm_debug_infer_path(160, B, H, W) == 7
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == lib.path
     x0 = hash_randn((B, 3, H, W), 5150).to(DEV)
     d.img_prev_upsample = (hash_randn((B, 3, H, W), 5151) * 0.5).clamp(-1, 1).to(DEV)
     outs = []
-    for on in (1, 0):
+    for on in (lib.mode, 0):
         lib.sinddm_debug_set_h2(on)
         torch.manual_seed(7)
         outs.append(d._run_steps(x0.clone(), s, list(range(40, 28, -1))).cpu())
-    lib.sinddm_debug_set_h2(1)
+    lib.sinddm_debug_set_h2(lib.mode)
     err = rel_l2(outs[0], outs[1])
-    print(f"[h2] 12 fused steps, h2 vs fp32-MFMA Winograd: {err:.3e}")
+    print(f"[h2 mode {lib.mode}] 12 fused steps, h2 vs fp32-MFMA Winograd: {err:.3e}")
     assert err < 2e-5

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 5, first contact of conv_h2: its parity tests, then C3/C2 A/B of the run-time switch on one box
+# round 5: parity tests of the binary16 kernels, then C3/C2 A/B of the run-time switch on one box
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd $ROOT; mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_h2.py -x -q -s -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -25 | tee gpurun_out/r5a_h2_tests.txt
-for v in 1 0; do
-  timeout 600 python bench.py --h2 $v --steps 10 --warmup 2 --no-cpu --no-full --no-train --no-strong 2>&1 | tail -1 > gpurun_out/r5a_bench_h2_$v.json
+timeout 1500 python -m pytest tests/test_gpu_h2.py -x -q -s -p no:cacheprovider 2>&1 | grep -v amdgpu.ids | tail -25 | tee gpurun_out/r5a_h2_tests.txt
+for v in 3 1 0; do
+  timeout 600 python bench.py --h2 $v --steps 10 --warmup 2 --no-cpu --no-full --no-train --no-strong --no-ab 2>&1 | tail -1 > gpurun_out/r5a_bench_h2_$v.json
   python - <<PY
 import json
 d=json.load(open("gpurun_out/r5a_bench_h2_$v.json")); r=d["roofline"]
