@@ -70,8 +70,6 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
     ap.add_argument("--no-ab", action="store_true", help="skip the fp32-MFMA A/B leg (fp32_mfma_path)")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--f44", type=int, default=None, choices=(0, 1),
-                    help="A/B only: force the F(4x4,3x3) kernel on / off (sinddm_debug_set_f44); default = the library's")
     ap.add_argument("--h2", type=int, default=None, choices=(0, 1, 3),
                     help="A/B only: binary16 hi/lo 3x3 kernels (sinddm_debug_set_h2): 0 off, 1 direct kernel only, 3 (default) Winograd + direct")
     return ap.parse_args()
@@ -304,7 +302,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     mix = {}
-    for gen, name in ((8, "conv_wh_kernel"), (7, "conv_h2_kernel"), (6, "conv_wino6_kernel"), (4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"), (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
+    for gen, name in ((8, "conv_wh_kernel"), (7, "conv_h2_kernel"), (4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"), (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
         g_ms, g_n, _, _ = _prof(lib, 10 + gen, 0)
         if g_n:
             mix[name] = {"launches": int(g_n), "avg_launch_ms": round(g_ms / g_n, 4)}
@@ -318,8 +316,9 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     algorithmic = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_ex / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic, traffic_src = _traffic(cfg_name)
-    h2_only = list(mix) == ["conv_h2_kernel"]
-    fp32_only = "conv_h2_kernel" not in mix
+    F16_KERNELS = ("conv_wh_kernel", "conv_h2_kernel")
+    h2_only = len(mix) > 0 and all(k in F16_KERNELS for k in mix)
+    fp32_only = not any(k in F16_KERNELS for k in mix)
     common = {
         "bound": "mfma",
         "kernel_mix": mix,
@@ -339,18 +338,28 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
         "net_tflops_whole_step": round(NET_FLOP_PER_PIXEL * px * steps / dt / 1e12, 2),
     }
     if h2_only:
+        wh = "conv_wh_kernel" in mix
         roofline = {
-            "kernel": "conv_h2_kernel: direct implicit-GEMM 3x3 conv on v_mfma_f32_32x32x16_f16, fp32 operands split into two "
-                      "binary16 pieces, three MFMA terms per product, fp32 accumulate (7 launches per step)",
+            "kernel": ("conv_wh_kernel: Winograd F(2x4,3x3) whose 24 frequency GEMMs run on v_mfma_f32_16x16x32_f16 -- transformed input and "
+                       "transformed weights each split into two binary16 pieces, all four MFMA terms, fp32 accumulate (7 launches per step)"
+                       if wh else
+                       "conv_h2_kernel: direct implicit-GEMM 3x3 conv on v_mfma_f32_32x32x16_f16, fp32 operands split into two "
+                       "binary16 pieces, three MFMA terms per product, fp32 accumulate (7 launches per step)")
+                      + "; this run's launches by kernel: " + ", ".join(f"{k} x{v['launches']}" for k, v in mix.items()),
             "achieved": round(executed, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
-            "flops_counted": "binary16 MFMA FLOPs as executed: 3 terms x 2*9*Cin*Cout per pixel on whole 8x64-pixel items and "
-                             "32-channel column tiles (C_out = 80 runs as 96)",
+            "flops_counted": ("binary16 MFMA FLOPs as executed: 4 terms x 24 frequencies per 8 outputs (= 12 MACs per pixel, ci, co instead "
+                              "of the direct form's 9) on whole 8x32-pixel items" if wh else
+                              "binary16 MFMA FLOPs as executed: 3 terms x 2*9*Cin*Cout per pixel on whole 8x64-pixel items and "
+                              "32-channel column tiles (C_out = 80 runs as 96)"),
+            "note": "the kernel is bound by the socket's power limit and by operand delivery (U fragments out of L2, input transform), "
+                    "not by the matrix pipe: see roofline.power, fp32_equivalent and DESIGN.md section 5",
             # the same launches priced as fp32 work (direct-convolution FLOPs / time) against both peaks the judge asked for
             "fp32_equivalent": {"achieved": round(algorithmic, 2), "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                                 "frac_of_fp32_mfma_peak": round(algorithmic / FP32_MFMA_PEAK_TFLOPS, 4),
-                                "split_scheme_peak": round(F16_MFMA_PEAK_TFLOPS / 3, 1),
-                                "frac_of_split_scheme_peak": round(algorithmic / (F16_MFMA_PEAK_TFLOPS / 3), 4)},
+                                # ceiling of the split scheme: direct form 3 terms per product; Winograd F(2x4) 4 terms on 1/3 of the products
+                                "split_scheme_peak": round(F16_MFMA_PEAK_TFLOPS * (3.0 / 4.0 if wh else 1.0 / 3.0), 1),
+                                "frac_of_split_scheme_peak": round(algorithmic / (F16_MFMA_PEAK_TFLOPS * (3.0 / 4.0 if wh else 1.0 / 3.0)), 4)},
             # what the binary16 pipe sustains for seconds at the socket's power limit with this kernel's LDS operand stream
             "sustained_ceiling": {"tflops": F16_MFMA_SUSTAINED_TFLOPS, "frac": round(executed / F16_MFMA_SUSTAINED_TFLOPS, 4),
                                   "source": "profiles/r05b_h2_power.txt (tools/ubench/h2_power.hip)"},
@@ -591,8 +600,6 @@ def main():
     lib = _lib.load()
     if args.h2 is not None:
         lib.sinddm_debug_set_h2(args.h2)
-    if args.f44 is not None and lib.sinddm_debug_set_f44(args.f44) < 0:
-        raise SystemExit("--f44: this library was built without the F(4x4) kernel (-DSINDDM_WINO_F44_BUILD=1)")
 
     from sinddm_amd.dist import shard_sizes
 
@@ -629,15 +636,17 @@ def main():
     torch.cuda.empty_cache()
     # the same steps on the fp32-MFMA Winograd path (the binary16 hi/lo kernel switched off), same process, same box
     fp32_path = None
-    if args.h2 is None and not args.no_ab and "conv_h2_kernel" in head["roofline"]["kernel_mix"]:
-        lib.sinddm_debug_set_h2(0)
-        ra, st_a = steps_leg(ctx, lib, cfg_name, B, min(args.steps, 10), min(args.warmup, 2), args.seed, G)
-        lib.sinddm_debug_set_h2(1)
-        del st_a
-        torch.cuda.empty_cache()
-        fp32_path = {"ms_per_step": ra["ms_per_step"], "value": ra["value"], "kernel_mix": ra["roofline"]["kernel_mix"],
-                     "frac_of_fp32_mfma_peak": ra["roofline"]["frac"], "power": ra["roofline"]["power"],
-                     "note": "sinddm_debug_set_h2(0): Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32, the round-4 path"}
+    if args.h2 is None and not args.no_ab and any(k in head["roofline"]["kernel_mix"] for k in ("conv_wh_kernel", "conv_h2_kernel")):
+        fp32_path = {}
+        for mode, key, note in ((0, "fp32_winograd", "sinddm_debug_set_h2(0): Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32, the round-4 path"),
+                                (1, "binary16_direct", "sinddm_debug_set_h2(1): conv_h2_kernel, direct implicit GEMM, 3 binary16 terms")):
+            lib.sinddm_debug_set_h2(mode)
+            ra, st_a = steps_leg(ctx, lib, cfg_name, B, min(args.steps, 10), min(args.warmup, 2), args.seed, G)
+            del st_a
+            torch.cuda.empty_cache()
+            fp32_path[key] = {"ms_per_step": ra["ms_per_step"], "value": ra["value"], "kernel_mix": ra["roofline"]["kernel_mix"],
+                              "frac": ra["roofline"]["frac"], "peak": ra["roofline"]["peak"], "power": ra["roofline"]["power"], "note": note}
+        lib.sinddm_debug_set_h2(3)
 
     nested = {}
     if not args.no_strong and not strong:
@@ -693,8 +702,11 @@ def main():
             "ms_per_step": head["ms_per_step"], "ms_per_step_rank_min_max": head["ms_per_step_rank_min_max"],
             "steps_per_sec_per_gpu": head["steps_per_sec_per_gpu"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": ("f32 (3x3 convs: binary16 hi/lo split products, 3 MFMA terms, fp32 accumulate -- fp32-equivalent, "
-                      "tests/test_gpu_h2.py; everything else fp32)" if "conv_h2_kernel" in head["roofline"]["kernel_mix"] else "f32"),
+            "dtype": ("f32 (3x3 convs: binary16 hi/lo split products -- Winograd-domain GEMMs with all 4 MFMA terms, fp32 accumulate; "
+                      "fp32-equivalent, error vs float64 = the fp32 oracle's: tests/test_gpu_h2.py; everything else fp32)"
+                      if "conv_wh_kernel" in head["roofline"]["kernel_mix"] else
+                      ("f32 (3x3 convs: binary16 hi/lo split products, 3 MFMA terms, fp32 accumulate -- fp32-equivalent, "
+                       "tests/test_gpu_h2.py; everything else fp32)" if "conv_h2_kernel" in head["roofline"]["kernel_mix"] else "f32")),
             "data": "synthetic (closed-form weights of the dim=160 architecture, torch.randn noise/images)",
             "config": {"workload": head["workload"], "batch_per_gpu": B, "global_batch": head["global_batch"],
                        "shards": sizes, "finest_hw": [H, W], "scale": s,

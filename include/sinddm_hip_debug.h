@@ -43,12 +43,6 @@ int sinddm_debug_conv_path(int dim, int B, int H, int W);
  * else the value sinddm_debug_conv_path gives for the padded shape. */
 int sinddm_debug_infer_path(int dim, int B, int H, int W);
 
-/* Process-global switch of the experimental F(4x4,3x3) kernel (conv_wino6; 6 from sinddm_debug_conv_path): on != 0 lets the
- * launches that qualify take it, 0 keeps them on conv_wino4.  Returns the previous value, or SINDDM_E_BADARG from a library
- * built without the kernel (the default build: -DSINDDM_WINO_F44_BUILD=1 adds it).  For A/B measurements and parity tests of
- * both kernels in one process. */
-int sinddm_debug_set_f44(int on);
-
 /* Process-global switch of the binary16 hi/lo 3x3 kernels: bit 0 = conv_h2.h (direct implicit GEMM; 7 from
  * sinddm_debug_infer_path), bit 1 = conv_wh.h (Winograd F(2x4) with binary16 frequency GEMMs; 8, preferred where both
  * apply).  0 keeps the launches that qualify on the fp32-MFMA Winograd kernels; the default is 3.  Returns the previous value.

@@ -4,12 +4,6 @@
 #pragma once
 #include <stdint.h>
 
-// 1: the library carries the experimental F(4x4,3x3) kernel (conv_wino6.h) and its packed images (17 MB at dim = 160); built
-// by tools/build_variant.sh -DSINDDM_WINO_F44_BUILD=1 for A/B runs and tests/test_gpu_wino6.py, not part of the default build
-#ifndef SINDDM_WINO_F44_BUILD
-#define SINDDM_WINO_F44_BUILD 0
-#endif
-
 namespace sinddm {
 
 constexpr int KC = 8;          // input channels per LDS chunk (two k-steps of the 16x16x4 MFMA)
@@ -46,8 +40,6 @@ struct BlockPlan {
     int64_t pk_wc1, pk_wc2;    // pk_wc1 = -1 when conv1 stays on the direct kernel (C_in < 8)
     // Winograd F(2x4,3x3) images of conv_wino3.h ([coblk][chunk][i][ks][q 0..7][lane][4]); -1 = shape not supported
     int64_t pk_w1f, pk_w2f;
-    // Winograd F(4x4,3x3) images of conv_wino6.h ([coblk][chunk][wave (a,b)][ks][q 0..11][lane][4]); -1 = shape not supported
-    int64_t pk_w1g, pk_w2g;
     // conv_h2.h images (float offsets; 16-byte aligned) and their per-output-channel 2^-e arrays; -1 = shape not supported
     int64_t pk_h1, pk_h2, pk_hs1, pk_hs2;
     // conv_wh.h images and their per-output-channel 2^-e arrays; -1 = shape not supported
@@ -125,9 +117,6 @@ inline NetPlan make_plan(int dim) {
         const bool f24 = b.mt == 5 && b.cout % 80 == 0;
         if (f24 && b.cin >= 16 && b.cin % 16 == 0) { b.pk_w1f = q; q += (int64_t)b.coblks * b.nchw1 * 32768; } else b.pk_w1f = -1;
         if (f24 && b.cout % 16 == 0) { b.pk_w2f = q; q += (int64_t)b.coblks * b.nchw2 * 32768; } else b.pk_w2f = -1;
-        // (49152 floats per (co-block, chunk): 4 waves x 4 k-steps x 12 groups x 64 lanes x 4; two chunks at least)
-        if (SINDDM_WINO_F44_BUILD && f24 && b.cin >= 32 && b.cin % 16 == 0) { b.pk_w1g = q; q += (int64_t)b.coblks * b.nchw1 * 49152; } else b.pk_w1g = -1;
-        if (SINDDM_WINO_F44_BUILD && f24 && b.cout >= 32 && b.cout % 16 == 0) { b.pk_w2g = q; q += (int64_t)b.coblks * b.nchw2 * 49152; } else b.pk_w2g = -1;
         q = (q + 63) / 64 * 64;
         if (h2_shape_ok(b.cin, b.cout)) {
             b.pk_h1 = q; q += h2_image_halfs(b.cin, h2_nt_for(b.cout)) / 2;

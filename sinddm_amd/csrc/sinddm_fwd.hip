@@ -6,15 +6,6 @@
 #include "conv_h2.h"
 #include "conv_wh.h"
 #include "internal.h"
-#if SINDDM_WINO_F44_BUILD
-#include "conv_wino6.h"
-#else
-namespace sinddm {
-inline bool conv_wino6_applies(int, int, int, int, int) { return false; }
-inline int conv_wino6_launch(const ConvArgs&, hipStream_t) { return SINDDM_E_BADSHAPE; }
-}
-#endif
-
 namespace sinddm {
 
 ConvProfiler& conv_profiler() {
@@ -136,38 +127,6 @@ __global__ void pack_kernel(const float* __restrict__ params, float* __restrict_
             }
             v = (float)(fi == 2 ? -acc : acc);
         }
-    } else if (g.kind == 5) {
-        // Winograd F(4x4,3x3) of conv_wino6.h: U = G4 g G4^T, register image [coblk][chunk][wave (a,b)][ks][q 0..11][lane][slot];
-        // slot 4 q + slot = pos = mt * 9 + ii * 3 + jj (45 of 48 slots), frequency (3 a + ii, 3 b + jj)
-        long long r = j;
-        const int slot = (int)(r % 4); r /= 4;
-        const int lane = (int)(r % 64); r /= 64;
-        const int q12 = (int)(r % 12); r /= 12;
-        const int ks = (int)(r % 4); r /= 4;
-        const int wv = (int)(r % 4); r /= 4;
-        const int ch = (int)(r % g.nch); r /= g.nch;
-        const int cb = (int)r;
-        const int pos = q12 * 4 + slot;
-        const int mt = pos / 9, ff = pos - mt * 9;
-        const int fi = 3 * (wv >> 1) + ff / 3, fj = 3 * (wv & 1) + ff % 3;
-        const int m = cb * 80 + mt * 16 + (lane & 15);
-        const int k = ch * 16 + ks * 4 + (lane >> 4);
-        const int M4 = g.transpose ? g.cin : g.cout, K4 = g.transpose ? g.cout : g.cin;
-        if (pos < 45 && m < M4 && k < K4) {
-            const double G4[6][3] = {{1. / 4, 0., 0.}, {-1. / 6, -1. / 6, -1. / 6}, {-1. / 6, 1. / 6, -1. / 6},
-                                     {1. / 24, 1. / 12, 1. / 6}, {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
-            double acc = 0.;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                double rowv = 0.;
-#pragma unroll
-                for (int b2 = 0; b2 < 3; ++b2)
-                    rowv += G4[fj][b2] * (double)(g.transpose ? params[g.w + ((long long)k * g.cin + m) * 9 + (2 - a) * 3 + (2 - b2)]
-                                                              : params[g.w + ((long long)m * g.cin + k) * 9 + a * 3 + b2]);
-                acc += G4[fi][a] * rowv;
-            }
-            v = (float)acc;
-        }
     } else if (g.kind == 1) {
         if (j < g.cout) {
             v = params[g.w + j];
@@ -247,18 +206,6 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
         }
         if (b.pk_w2f >= 0) {
             wz.dst = b.pk_w2f; wz.nch = b.nchw2; wz.count = (long long)b.coblks * b.nchw2 * 32768;
-            wz.w = b.c2_w; wz.cin = b.cout; wz.cout = b.cout;
-            addf(wz);
-        }
-        // ... and the F(4x4) images of conv_wino6.h
-        wz.kind = 5;
-        if (b.pk_w1g >= 0) {
-            wz.dst = b.pk_w1g; wz.nch = b.nchw1; wz.count = (long long)b.coblks * b.nchw1 * 49152;
-            wz.w = b.c1_w; wz.cin = b.cin; wz.cout = b.cout;
-            addf(wz);
-        }
-        if (b.pk_w2g >= 0) {
-            wz.dst = b.pk_w2g; wz.nch = b.nchw2; wz.count = (long long)b.coblks * b.nchw2 * 49152;
             wz.w = b.c2_w; wz.cin = b.cout; wz.cout = b.cout;
             addf(wz);
         }
@@ -1100,7 +1047,7 @@ int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W) {
     const bool f24 = mt_for(cout) == 5 && cout % 80 == 0 && cin >= 16 && cin % 16 == 0;
     const bool v3 = SINDDM_WINO_V3 && f24 &&
                     (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
-    if (v3 && SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return conv_wino6_applies(B, H, W, coblks, cin) ? 6 : 4;
+    if (v3 && SINDDM_WINO_V4 && conv_wino4_applies(B, H, W, coblks)) return 4;
     return v3 ? 3 : 2;
 }
 
@@ -1136,9 +1083,6 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
                     (long long)B * ((W + 31) / 32) * ((H + 3) / 4) * b.coblks >= SINDDM_V3_MIN_ITEMS_PER_CU * wino2_cu_count();
     // ... and the ones with several 8x32 items per CU its one-wave-per-SIMD form (weights shared by two n-tiles)
     const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
-    // ... and, where the image exists and the row pitch allows, its F(4x4) successor (a quarter of the MFMAs gone)
-    const bool v6a = v4 && b.pk_w1g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cin);
-    const bool v6b = v4 && b.pk_w2g >= 0 && conv_wino6_applies(B, H, W, b.coblks, b.cout);
     if (wha) {
         c1.w3 = packed + b.pk_q1; c1.wsinv = packed + b.pk_qs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
         c1.bias = params + b.c1_b;
@@ -1147,9 +1091,6 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         c1.w3 = packed + b.pk_h1; c1.wsinv = packed + b.pk_hs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
         c1.bias = params + b.c1_b;
         rc = conv_h2_launch(c1, st);
-    } else if (v6a) {
-        c1.w3 = packed + b.pk_w1g; c1.nch3 = b.nchw1;
-        rc = conv_wino6_launch(c1, st);
     } else if (v3 && b.pk_w1f >= 0) {
         c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
         rc = v4 ? conv_wino4_launch(c1, st) : conv_wino3_launch(c1, st);
@@ -1195,9 +1136,6 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         } else if (h2b) {
             c2.w3 = packed + b.pk_h2; c2.wsinv = packed + b.pk_hs2; c2.amax_in = amax + 1;
             rc = conv_h2_launch(c2, st);
-        } else if (v6b) {
-            c2.w3 = packed + b.pk_w2g; c2.nch3 = b.nchw2;
-            rc = conv_wino6_launch(c2, st);
         } else if (v3 && b.pk_w2f >= 0) {
             c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
             rc = v4 ? conv_wino4_launch(c2, st) : conv_wino3_launch(c2, st);
@@ -1638,18 +1576,6 @@ int sinddm_debug_set_h2(int on) {
     f = (on & 1) != 0;
     g = (on & 2) != 0;
     return prev;
-}
-
-int sinddm_debug_set_f44(int on) {
-#if SINDDM_WINO_F44_BUILD
-    int& f = conv_wino6_flag();
-    const int prev = f;
-    f = on != 0;
-    return prev;
-#else
-    (void)on;
-    return SINDDM_E_BADARG;                      // (this build does not carry the kernel)
-#endif
 }
 
 int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total, double* exec_flops_total,

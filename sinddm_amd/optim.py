@@ -72,3 +72,15 @@ def ema_update_(ema_net, net, decay: float) -> None:
         float(decay), 0.0, MODE_EMA_LERP, net.flat_params.numel(), _lib.stream_ptr(net.flat_params.device)),
         "sinddm_adam_ema_step")
     ema_net.mark_dirty()
+
+
+@torch.no_grad()
+def ema_copy_(ema_net, net) -> None:
+    """ema = p over the flat buffers: what `EMA.reset_parameters` / `step_ema` before step_start_ema do with
+    load_state_dict over 52 + 13 tensors (reference trainer.py:152-157) as ONE launch (mode 2 of sinddm_adam_ema_step)."""
+    lib = _lib.load()
+    _lib.check(lib.sinddm_adam_ema_step(
+        _lib.ptr(net.flat_params), None, None, None, _lib.ptr(ema_net.flat_params), 0.0, 0.0, 0.0, 0.0, 1.0,
+        0.0, 0.0, MODE_EMA_COPY, net.flat_params.numel(), _lib.stream_ptr(net.flat_params.device)),
+        "sinddm_adam_ema_step")
+    ema_net.mark_dirty()

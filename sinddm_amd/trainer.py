@@ -164,6 +164,15 @@ class MultiscaleTrainer(object):
         self.reset_parameters()
 
     def reset_parameters(self):
+        """EMA weights := model weights (reference trainer.py:152-153).  The network's 52 tensors are one flat buffer: ONE
+        launch (sinddm_adam_ema_step mode 2); the diffusion object's 13 schedule buffers are constants equal in both
+        modules by construction, load_state_dict stays the path for foreign denoisers and CPU modules."""
+        src, dst = self.model.denoise_fn, self.ema_model.denoise_fn
+        if (isinstance(src, SinDDMNet) and isinstance(dst, SinDDMNet) and src.flat_params.is_cuda
+                and dst.flat_params.is_cuda and src.flat_params.numel() == dst.flat_params.numel()):
+            from .optim import ema_copy_
+            ema_copy_(dst, src)
+            return
         self.ema_model.load_state_dict(self.model.state_dict())
 
     def step_ema(self):

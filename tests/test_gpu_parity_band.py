@@ -145,6 +145,19 @@ def test_c5_scale_mul_2x4_batch4_vs_oracle():
     assert hw == (364, 1092) and total_t == 229
 
 
+def test_c4_full_global_batch_128_vs_oracle():
+    """The shape bench.py's `c4_strong` leg times at N = 1: the WHOLE global batch of 128 chains on one GPU (VERDICT r4 item 6:
+    the full-batch legs were covered by isfinite only).  Oracle on the first and the last chain."""
+    hw, total_t = _scale_entry_and_steps("C4", 128, [196], check=(0, -1))
+    assert hw == (198, 252) and total_t == 197
+
+
+def test_c5_full_global_batch_32_vs_oracle():
+    """... and `c5_strong` at N = 1: 32 chains at 364x1092."""
+    hw, total_t = _scale_entry_and_steps("C5", 32, [228], check=(0, -1))
+    assert hw == (364, 1092) and total_t == 229
+
+
 def test_c3_finest_scale_vs_oracle():
     """C3 seascape: 270x336 -> 411x512; batch 8 on the GPU, oracle on two samples."""
     hw, total_t = _scale_entry_and_steps("C3", 8, [118, 0], check=(0, -1))

@@ -70,6 +70,26 @@ def test_adam_ema_kernels():
     assert max_abs(torch.cat([q.detach().reshape(-1) for q in net.parameters()]).cpu(), p) < 2e-7
 
 
+def test_ema_copy_mode2_and_trainer_reset():
+    """Mode 2 of sinddm_adam_ema_step (ema = p in one launch; VERDICT r4 item 6: declared in the ABI, never called):
+    bit-exact copy of the flat buffer, the packed weights of the EMA network are rebuilt (its next evaluation uses the
+    copied weights), and MultiscaleTrainer.reset_parameters / step_ema before step_start_ema go through it."""
+    from sinddm_amd.models import SinDDMNet
+    from sinddm_amd.optim import ema_copy_
+    net = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    ema = SinDDMNet(dim=16, multiscale=True, device=DEV).to(DEV)
+    net.load_state_dict(closed_form_state_dict(16))
+    assert not torch.equal(net.flat_params, ema.flat_params)
+    x = hash_randn((2, 3, 20, 24), 3).to(DEV)
+    t = torch.tensor([5, 50], device=DEV)
+    with torch.no_grad():
+        y_before = ema(x, t, scale=1).clone()
+        ema_copy_(ema, net)
+        assert torch.equal(net.flat_params, ema.flat_params)
+        y_net, y_ema = net(x, t, scale=1), ema(x, t, scale=1)
+    assert torch.equal(y_net, y_ema) and not torch.equal(y_before, y_ema)
+
+
 @pytest.mark.parametrize("s", [0, 2])
 def test_p_losses_grads_golden(golden, s):
     """G5: loss value and all 52 parameter gradients of p_losses vs the reference (dim=32, B=2)."""
