@@ -362,8 +362,18 @@ inline int& conv_h2_flag() {
     return on;
 }
 
+// ... and of conv_wh.h (bit 1 of sinddm_debug_set_h2): 0 = its launches stay on conv_h2 / the fp32 kernels
+inline int& conv_wh_flag() {
+    static int on = 1;
+    return on;
+}
+
 inline bool conv_h2_applies(int B, int H, int W, int cin, int cout) {
     if (!SINDDM_CONV_H2 || !conv_h2_flag() || !h2_shape_ok(cin, cout) || W % 4 != 0) return false;
+    // With the Winograd binary16 kernel enabled (the default) this kernel takes no launch: where conv_wh does not apply
+    // (fewer than 20 items per CU) the fp32 Winograd kernels are faster than the direct form (profiles/r05_scales.txt:
+    // 76x95 at batch 64: 81.6 against 115.4 Mpx-steps/s).  It stays the A/B reference (switch value 1) of bench.py and the tests.
+    if (conv_wh_flag()) return false;
     if ((long long)cin * H * W * 4 >= 0x40000000LL) return false;      // (one sample's input is addressed as a 32-bit buffer)
     return (long long)B * ((W + H2_TW - 1) / H2_TW) * ((H + H2_TH - 1) / H2_TH) >=
            (long long)SINDDM_H2_MIN_ITEMS_PER_CU * wino2_cu_count();

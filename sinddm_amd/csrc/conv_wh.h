@@ -556,17 +556,11 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
 }
 
 #ifndef SINDDM_WH_MIN_ITEMS_PER_CU
-#define SINDDM_WH_MIN_ITEMS_PER_CU 2
+#define SINDDM_WH_MIN_ITEMS_PER_CU 20      // measured per pyramid scale (profiles/r05_scales.txt): 15 items per CU lose to conv_wino4, 24 win
 #endif
 #ifndef SINDDM_CONV_WH
 #define SINDDM_CONV_WH 1
 #endif
-// Run-time switch (process-global, sinddm_debug_set_h2 bit 1): 0 = the launches stay on conv_h2 / the fp32 kernels
-inline int& conv_wh_flag() {
-    static int on = 1;
-    return on;
-}
-
 inline bool conv_wh_applies(int B, int H, int W, int cin, int cout) {
     if (!SINDDM_CONV_WH || !conv_wh_flag() || !wh_shape_ok(cin, cout) || W % 4 != 0) return false;
     if ((long long)cin * H * W * 4 >= 0x40000000LL) return false;      // (one sample's input is addressed as a 32-bit buffer)

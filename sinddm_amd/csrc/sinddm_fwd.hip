@@ -1399,6 +1399,10 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
     const long long rounds = (items + ncu - 1) / ncu;
     bool split = sx != nullptr && sx != st && B >= 2 && fuse_tail && n_steps > 0 && items < SINDDM_SPLIT_ITEMS_HI * ncu &&
                  items >= SINDDM_SPLIT_ITEMS_LO * ncu && (rounds * ncu - items) * 25 >= rounds * ncu;
+    // (a batch whose 3x3 convs take the binary16 kernels stays whole: its halves could fall below their items-per-CU
+    // threshold and run on the fp32 kernels -- the same chain would then round differently with and without a second stream)
+    if (split && (conv_wh_applies(B, H, fwd_pitch(p, W), p.dim, p.dim) || conv_h2_applies(B, H, fwd_pitch(p, W), p.dim, p.dim)))
+        split = false;
     // (the two halves carve their own cores behind the shared conditioning table: only if that really fits -- ADVICE r4)
     if (split && cond_region_bytes(p, B) + fwd_workspace_core(p, (B + 1) / 2, H, W) + fwd_workspace_core(p, B - (B + 1) / 2, H, W) > ws_bytes)
         split = false;

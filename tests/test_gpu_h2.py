@@ -55,10 +55,11 @@ def h2_switch(request):
     lib.sinddm_debug_set_h2(prev)
 
 
-@pytest.mark.parametrize("B,H,W", [(8, 186, 248),      # C2 finest: W % 4 == 0, H % 8 = 2
-                                    (12, 133, 177),     # odd width: rows padded to 180, last item 52 columns wide
-                                    (3, 411, 512),      # C3 finest, exact 64-column items, H % 8 = 3
-                                    (24, 94, 126)])     # W % 4 = 2
+# (batches: conv_wh takes a launch from 20 items of 8x32 pixels x 80 channels per CU)
+@pytest.mark.parametrize("B,H,W", [(16, 186, 248),     # C2 finest at its benchmarked batch: W % 4 == 0, H % 8 = 2
+                                    (28, 133, 177),     # odd width: rows padded to 180, last item 20 columns wide
+                                    (4, 411, 512),      # C3 finest, exact items, H % 8 = 3
+                                    (56, 94, 126)])     # W % 4 = 2
 def test_error_vs_float64_not_wider_than_fp32(h2_switch, B, H, W):
     lib = h2_switch
     assert lib.sinddm_debug_infer_path(160, B, H, W) == lib.path
@@ -91,7 +92,7 @@ def test_dynamic_range(h2_switch, gain):
     so every later 3x3 conv sees inputs around `gain`.  The running-max scale must keep both binary16 pieces in range:
     same relative error as at gain 1."""
     lib = h2_switch
-    B, H, W = 8, 186, 248
+    B, H, W = 16, 186, 248
     sd = {k: v.clone() for k, v in closed_form_state_dict(160).items()}
     for k in ("l1.net.2.weight", "l1.net.2.bias", "l1.res_conv.weight", "l1.res_conv.bias"):
         sd[k] = sd[k] * gain

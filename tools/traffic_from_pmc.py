@@ -23,7 +23,7 @@ def per_launch(prefix, ps, counter):
             if r["Dispatch_Id"] not in disp[k]:
                 disp[k].add(r["Dispatch_Id"])
                 dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-    ks = [k for k in tot if "conv_wino" in k]
+    ks = [k for k in tot if "conv_wino" in k or "conv_wh" in k or "conv_h2" in k]
     n = sum(len(disp[k]) for k in ks)
     return (sum(tot[k] for k in ks) / n if n else 0.0), n, (sum(dur[k] for k in ks) / n if n else 0.0)
 
@@ -40,7 +40,7 @@ def main(prefix, tag):
             continue
         algb = sum(4.0 * (ci + co) * alg[cfg] for ci, co in chans) / len(chans)
         out[cfg.upper()] = {
-            "kernel": "conv_wino*_kernel (the 7 Winograd launches of a step pooled)", "launches_sampled": n,
+            "kernel": "the seven 3x3 launches of a step pooled (conv_wh_kernel / conv_h2_kernel / conv_wino*_kernel, whichever ran)", "launches_sampled": n,
             "source": f"profiles/{tag}_pmc_{cfg}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB)",
             "fetch_size_bytes_raw": fetch * 1024, "write_size_bytes_raw": write * 1024,
             "fetch_size_bytes_x2": 2 * fetch * 1024,
