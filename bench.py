@@ -296,9 +296,12 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     # steps with HIP events around every MFMA conv launch (on the launch stream)
     lib.sinddm_prof_begin()
     t0p = time.perf_counter()
+    two = d.two_streams
+    d.two_streams = False          # (one stream in the instrumented pass: the per-launch event times of two overlapping half-batches would add up to more than the step -- ADVICE r4)
     with _PowerSampler() as power:
         img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
         ctx.barrier()
+    d.two_streams = two
     dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     mix = {}

@@ -114,7 +114,10 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 v) {
     q = q * s + 1.0f;
     const f32x2 n = p * c + q;
     const f32x2 r{__builtin_amdgcn_rcpf(q.x), __builtin_amdgcn_rcpf(q.y)};
-    const f32x2 h = 0.5f * v;
+    // (the multiplier is v itself above the lower clamp and the clamp below it: for v < -4 sqrt 2 the quotient is 5e-7, not 0,
+    // and 0.5 v x 5e-7 would grow with |v|; held at the clamp the tail is the constant -1.4e-6, inside the bound above, as
+    // nn.GELU's tail decays to 0 -- ADVICE r4.  gelu_erf_grad keeps the Abramowitz-Stegun form: the two differ by <= 1e-6.)
+    const f32x2 h = 0.5f * __builtin_elementwise_max(v, f32x2{-CL, -CL});
     return (h * n) * r;
 }
 __device__ __forceinline__ float gelu_erf(float v) { return gelu_erf2(f32x2{v, v}).x; }
