@@ -216,19 +216,20 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     const int f0 = 4 * (service_rt ? 0 : wv);
     const int a_rd = ((kq & 1) * 16 + l16) * 16;
 
-    // persistent: XCD `xcd` owns a contiguous range of tiles; workgroup `ls` of the XCD takes tiles ls, ls + wg_per_xcd, ... and runs
-    // the co blocks of a tile back to back (the second pass over the raw tile finds it in L2)
+    // persistent: XCD `xcd` owns a contiguous range of tiles; its (tile, co block) items go round-robin over its workgroups, so
+    // the co blocks of one tile run at the same time on neighbouring workgroups of the XCD and the second reader of a raw tile
+    // finds it in the XCD's L2.  (Back to back on one workgroup the second pass came out of the Infinity Cache: 28 GB of
+    // fabric reads per C3 launch against 16 for conv_wino4, profiles/r05d_pmc_c3_summary.txt.)
     const int xcd = blockIdx.x & 7, ls = blockIdx.x >> 3;
     const int tpi = p.tilesX * p.tilesY;
-    (void)items_per_xcd;
     struct Item { int b, y0, x0, cb; bool ok; };
     auto decode = [&](int j) {
         Item it;
-        const int q = j / p.coblks;
-        it.cb = j - q * p.coblks;
-        const int tl = ls + q * wg_per_xcd;
+        const int li = ls + j * wg_per_xcd;
+        const int tl = li / p.coblks;
+        it.cb = li - tl * p.coblks;
         const int tile = xcd * p.tiles_per_xcd + tl;
-        it.ok = tl < p.tiles_per_xcd && tile < p.ntiles;
+        it.ok = li < items_per_xcd && tile < p.ntiles;
         const int tcl = it.ok ? tile : 0;
         it.b = tcl / tpi;
         const int trm = tcl - it.b * tpi;

@@ -194,18 +194,38 @@ def test_sampler_properties_full_size(golden):
 
 def test_large_batch_index_range():
     """C3 finest scale (B=64, 411x512): one 160-channel tensor has 2.15e9 elements > 2^31 -- the tail samples of the
-    big batch must equal the same samples run alone (32-bit index overflow would corrupt exactly those)."""
+    big batch must equal the same samples run alone (32-bit index overflow would corrupt exactly those).  The big batch
+    takes conv_wh (binary16 Winograd), two samples alone the fp32 Winograd kernels: equal to rounding under the default
+    path (an index error is O(1)), bit for bit with the binary16 kernels switched off (same kernel family both ways) and
+    bit for bit between the binary16 batch and a 16-sample sub-batch that also takes conv_wh (per-sample scales: a
+    sample does not see its neighbours)."""
+    from sinddm_amd import _lib
+    lib = _lib.load()
     net = _net(160)
     B, H, W = 64, 411, 512
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn(B, 3, H, W, device=DEV, generator=g)
     t = torch.randint(0, 1000, (B,), device=DEV, generator=g)
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 8 and lib.sinddm_debug_infer_path(160, 16, H, W) == 8
     with torch.no_grad():
         y = net(x, t, scale=5)
         y_tail = net(x[-2:].contiguous(), t[-2:].contiguous(), scale=5)
         y_head = net(x[:2].contiguous(), t[:2].contiguous(), scale=5)
+        y_sub = net(x[-16:].contiguous(), t[-16:].contiguous(), scale=5)
     assert torch.isfinite(y).all()
-    assert torch.equal(y[-2:], y_tail) and torch.equal(y[:2], y_head)
+    assert rel_l2(y[-2:].cpu(), y_tail.cpu()) < 2e-6 and rel_l2(y[:2].cpu(), y_head.cpu()) < 2e-6
+    assert torch.equal(y[-16:], y_sub)
+    del y_sub
+    prev = lib.sinddm_debug_set_h2(0)
+    try:
+        with torch.no_grad():
+            y0 = net(x, t, scale=5)
+            y0_tail = net(x[-2:].contiguous(), t[-2:].contiguous(), scale=5)
+            y0_head = net(x[:2].contiguous(), t[:2].contiguous(), scale=5)
+        assert torch.equal(y0[-2:], y0_tail) and torch.equal(y0[:2], y0_head)
+        assert rel_l2(y.cpu()[::21], y0.cpu()[::21]) < 2e-6
+    finally:
+        lib.sinddm_debug_set_h2(prev)
 
 
 @pytest.mark.parametrize("dim", [20, 28, 10])
