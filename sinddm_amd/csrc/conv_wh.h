@@ -45,6 +45,9 @@ __device__ __forceinline__ void wh_static_for(F&& f) {
 #ifndef WH_ABL
 #define WH_ABL 0
 #endif
+#ifndef WH_NT
+#define WH_NT 6                // bit 0: raw-tile loads non-temporal (measured: +8 %, the co blocks' sharing in L2 is lost), bit 1: epilogue residual loads, bit 2: output stores -- of tensors beyond the 256 MB last-level cache only (C3: -1.2 %, C2: +0.6 % without that rule)
+#endif
 #ifdef WH_TIMING
 // s_memtime stamps of every workgroup's third item (debug builds only; tools/wh_seg.py): [launch % 8][workgroup][wave][32]
 __device__ unsigned long long g_wh_seg[8 * 256 * 8 * 32];
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     const int HW = H * W;
     const int Wt = p.Wt > 0 ? p.Wt : W;
     const int nch = p.nch3;                                  // 16-channel chunks
+    const bool big_out = __builtin_amdgcn_readfirstlane((size_t)p.B * p.Cout * HW > ((size_t)1 << 28)) != 0;   // written / read once: non-temporal
     constexpr int OOB = 0x40000000;
     const bool service_rt = wv >= 6;                         // (two separate instantiations of the item loop below: nothing of one role is live in the other)
     const int sv = wv - 6;                                   // service wave 0 / 1
@@ -260,8 +264,8 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int so = (c * 16 + (sv & 1) * 8 + k) * HW * 4;
-            stg[2 * k] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[0], so, 0));
-            stg[2 * k + 1] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[1], so, 0));
+            stg[2 * k] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[0], so, (WH_NT & 1) ? 2 : 0));
+            stg[2 * k + 1] = (WH_ABL & 1) ? f32x4{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo[1], so, (WH_NT & 1) ? 2 : 0));
         }
     };
     auto stage_write = [&](unsigned char* raw) {
@@ -279,6 +283,12 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     Item cur = decode(0);
     if (!cur.ok) return;
     int svoff[2] = {OOB, OOB};
+#ifndef WH_SVC_PRIO
+#define WH_SVC_PRIO 2
+#endif
+    // (the service waves are the longest pole of a chunk and share their SIMDs with multiplying waves that mostly wait for
+    // memory: they win the issue arbitration)
+    if constexpr (service) __builtin_amdgcn_s_setprio(WH_SVC_PRIO);
     if constexpr (service) {                                 // the first item's first chunk
         stage_offsets(cur, svoff);
         stage_load(in_rsrc(cur.b), svoff, 0);
@@ -431,7 +441,8 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
                 for (int pp = 0; pp < 2; ++pp) {
                     rsd[n][pp] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (p.resid && !(WH_ABL & 16) && e_in && ey + pp < H)
-                        rsd[n][pp] = *reinterpret_cast<const f32x4*>(p.resid + ((size_t)b * p.Cout + co) * HW + (size_t)(ey + pp) * W + ex);
+                        rsd[n][pp] = ((WH_NT & 2) && big_out) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.resid + ((size_t)b * p.Cout + co) * HW + (size_t)(ey + pp) * W + ex))
+                                                 : *reinterpret_cast<const f32x4*>(p.resid + ((size_t)b * p.Cout + co) * HW + (size_t)(ey + pp) * W + ex);
                 }
             }
         };
@@ -541,7 +552,8 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[e]));
-                    *reinterpret_cast<f32x4*>(p.out + o) = v;
+                    if ((WH_NT & 4) && big_out) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.out + o));
+                    else *reinterpret_cast<f32x4*>(p.out + o) = v;
                 }
             }
         });

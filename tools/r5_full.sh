@@ -8,5 +8,6 @@ timeout 900 python bench.py > gpurun_out/bench_$TAG.log 2>&1
 tail -1 gpurun_out/bench_$TAG.log > gpurun_out/bench_$TAG.json
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-full --no-cpu --no-strong --no-train --no-ab > $ROOT/gpurun_out/prof_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_${TAG}_c3 -o bench -- python $ROOT/bench.py --config C3 --steps 10 --warmup 2 --no-full --no-cpu --no-strong --no-train --no-ab --no-c2 > $ROOT/gpurun_out/prof_${TAG}_c3.log 2>&1
 cd $ROOT
 tail -6 gpurun_out/tests_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log; tail -c 600 gpurun_out/bench_$TAG.json; echo; find gpurun_out/prof_$TAG -name "*stats*" | head
