@@ -38,7 +38,7 @@ int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flop
 int sinddm_debug_conv_path(int dim, int B, int H, int W);
 
 /* The same question for INFERENCE launches (sinddm_net_forward / sinddm_sample_chain: rows padded to 4 floats inside the
- * workspace): 8 = conv_wh (Winograd F(2x4), binary16 hi/lo frequency GEMMs: >= 20 items of 8x32 pixels x 80 channels per CU),
+ * workspace): 8 = conv_wh (Winograd F(2x4), binary16 hi/lo frequency GEMMs: >= 12 items of 8x32 pixels x 80 channels per CU, images of >= 12 000 pixels),
  * 7 = conv_h2 (binary16 hi/lo direct kernel: only with switch value 1, >= 2 items of 8x64 pixels per CU),
  * else the value sinddm_debug_conv_path gives for the padded shape. */
 int sinddm_debug_infer_path(int dim, int B, int H, int W);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     // persistent: XCD `xcd` owns a contiguous range of tiles; its (tile, co block) items go round-robin over its workgroups, so
     // the co blocks of one tile run at the same time on neighbouring workgroups of the XCD and the second reader of a raw tile
     // finds it in the XCD's L2.  (Back to back on one workgroup the second pass came out of the Infinity Cache: 28 GB of
-    // fabric reads per C3 launch against 16 for conv_wino4, profiles/r05d_pmc_c3_summary.txt.)
+    // fabric reads per C3 launch against 16 for conv_wino4, profiles/r05e_pmc_c3_summary.txt.)
     const int xcd = blockIdx.x & 7, ls = blockIdx.x >> 3;
     const int tpi = p.tilesX * p.tilesY;
     struct Item { int b, y0, x0, cb; bool ok; };
@@ -569,7 +569,11 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
 }
 
 #ifndef SINDDM_WH_MIN_ITEMS_PER_CU
-#define SINDDM_WH_MIN_ITEMS_PER_CU 20      // measured per pyramid scale (profiles/r05_scales.txt): 15 items per CU lose to conv_wino4, 24 win
+#define SINDDM_WH_MIN_ITEMS_PER_CU 12      // measured per pyramid scale (profiles/r05_scales.txt, r05_threshold_ab_full.txt): C2 133x177 at batch 16
+#endif
+#ifndef SINDDM_WH_MIN_PIXELS
+#define SINDDM_WH_MIN_PIXELS 12000          // (12.75 items per CU) wins on conv_wh, C3 76x95 at batch 64 (15 per CU, 7 220 pixels: the whole working set of a launch
+                                           // lives in the last-level cache and conv_wino4's memory phases are cheap) loses 10 %
 #endif
 #ifndef SINDDM_CONV_WH
 #define SINDDM_CONV_WH 1
@@ -577,6 +581,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
 inline bool conv_wh_applies(int B, int H, int W, int cin, int cout) {
     if (!SINDDM_CONV_WH || !conv_wh_flag() || !wh_shape_ok(cin, cout) || W % 4 != 0) return false;
     if ((long long)cin * H * W * 4 >= 0x40000000LL) return false;      // (one sample's input is addressed as a 32-bit buffer)
+    if ((long long)H * W < SINDDM_WH_MIN_PIXELS) return false;
     return (long long)B * ((W + WH_TW - 1) / WH_TW) * ((H + WH_TH - 1) / WH_TH) * (cout / WH_COB) >=
            (long long)SINDDM_WH_MIN_ITEMS_PER_CU * wino2_cu_count();
 }

@@ -55,7 +55,7 @@ def h2_switch(request):
     lib.sinddm_debug_set_h2(prev)
 
 
-# (batches: conv_wh takes a launch from 20 items of 8x32 pixels x 80 channels per CU)
+# (batches: conv_wh takes a launch from 12 items of 8x32 pixels x 80 channels per CU)
 @pytest.mark.parametrize("B,H,W", [(16, 186, 248),     # C2 finest at its benchmarked batch: W % 4 == 0, H % 8 = 2
                                     (28, 133, 177),     # odd width: rows padded to 180, last item 20 columns wide
                                     (4, 411, 512),      # C3 finest, exact items, H % 8 = 3
