@@ -45,6 +45,9 @@ __device__ __forceinline__ void wh_static_for(F&& f) {
 #ifndef WH_ABL
 #define WH_ABL 0
 #endif
+#ifndef WH_SPLIT_IN_M
+#define WH_SPLIT_IN_M 0        // 1: the service waves write V as fp32 and the multiplying waves split it on the way into the MFMA.  Measured
+#endif                         //    (profiles/r05_wh_split_in_multiply_ab.txt): 8 % fewer cycles per item, 100 MHz less clock: C3 +1.4 %, C2 -1.3 %
 #ifndef WH_NT
 #define WH_NT 6                // bit 0: raw-tile loads non-temporal (measured: +8 %, the co blocks' sharing in L2 is lost), bit 1: epilogue residual loads, bit 2: output stores -- of tensors beyond the 256 MB last-level cache only (C3: -1.2 %, C2: +0.6 % without that rule)
 #endif
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     // M-phase role: frequencies 4 wv + (0..3).  V fragment of (f, mg, piece): lane (tile l16, k group kq) reads the 16 bytes of
     // channel half kq & 1 -- the same bytes for kq and kq + 2 (LDS broadcast): K = 32 = [V | V] against [U_hi | U_lo]
     const int f0 = 4 * (service_rt ? 0 : wv);
-    const int a_rd = ((kq & 1) * 16 + l16) * 16;
+    const int a_rd = WH_SPLIT_IN_M ? ((kq & 1) * 32 + l16) * 16 : ((kq & 1) * 16 + l16) * 16;
+    const int t_wr1 = t_mg * 1024 + (((sv & 1) * 2 + t_q) * 16 + t_t16) * 16;             // fp32 V: [f][mg][k half][channel quad][tile][4 floats]
 
     // persistent: XCD `xcd` owns a contiguous range of tiles; its (tile, co block) items go round-robin over its workgroups, so
     // the co blocks of one tile run at the same time on neighbouring workgroups of the XCD and the second reader of a raw tile
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
             wh_static_for<2>([&](auto HS) {
                 constexpr int hs = decltype(HS)::value;
                 const unsigned char* rp = raw + t_rd0 + hs * WH_RS * 4;
-                unsigned char* wp = vb + t_wr0 + hs * (12 * 2048);
+                unsigned char* wp = vb + (WH_SPLIT_IN_M ? t_wr1 : t_wr0) + hs * (12 * 2048);
                 // rows r0 .. r0+2 (r0 = 2 tr + hs) of the patch, its columns = LDS columns 4 tc + 3 .. + 8, four channels as two
                 // packed pairs
                 f32x2 d[2][3][6];
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
                     // vertical B^T (F(2,3)): i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; this task's rows start at hs
                     //   hs = 0: i = 0 -> d[0] - d[2];  i = 1 -> d[1] + d[2]        hs = 1: i = 2 -> d[1] - d[0];  i = 3 -> d[0] - d[2]
                     h16x2 hi[2][6], lo[2][6];
+                    f32x2 vs[2][6];
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
                         f32x2 r[6];
@@ -353,14 +358,21 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
 #pragma unroll
                         for (int j = 0; j < 6; ++j) {
                             const f32x2 sc = v[j] * sx2;
-                            hi[pr][j] = __builtin_convertvector(sc, h16x2);
-                            const f32x2 rem = sc - __builtin_convertvector(hi[pr][j], f32x2);
-                            lo[pr][j] = __builtin_convertvector(rem, h16x2);
+                            vs[pr][j] = sc;
+                            if (!WH_SPLIT_IN_M) {
+                                hi[pr][j] = __builtin_convertvector(sc, h16x2);
+                                const f32x2 rem = sc - __builtin_convertvector(hi[pr][j], f32x2);
+                                lo[pr][j] = __builtin_convertvector(rem, h16x2);
+                            }
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         using h16x4 = __attribute__((ext_vector_type(4))) _Float16;
+                        if (WH_SPLIT_IN_M) {
+                            *reinterpret_cast<f32x4*>(wp + (ii * 6 + j) * 2048) = f32x4{vs[0][j][0], vs[0][j][1], vs[1][j][0], vs[1][j][1]};
+                            continue;
+                        }
                         *reinterpret_cast<h16x4*>(wp + (ii * 6 + j) * 2048) = h16x4{hi[0][j][0], hi[0][j][1], hi[1][j][0], hi[1][j][1]};
                         *reinterpret_cast<h16x4*>(wp + (ii * 6 + j) * 2048 + 512) = h16x4{lo[0][j][0], lo[0][j][1], lo[1][j][0], lo[1][j][1]};
                     }
@@ -393,10 +405,30 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
             const unsigned char* A = vb + f0 * 2048 + a_rd;
             wh_static_for<4>([&](auto FI) {
                 constexpr int fi = decltype(FI)::value;
-                const h16x8 ah0 = *reinterpret_cast<const h16x8*>(A + fi * 2048);
-                const h16x8 ah1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024);
-                const h16x8 al0 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 512);
-                const h16x8 al1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024 + 512);
+                h16x8 ah0, ah1, al0, al1;
+                if (WH_SPLIT_IN_M) {
+                    // 8 fp32 values of V (channels 8 (kq & 1) + 0..7 of this lane's tile) -> hi = rn16(v), lo = rn16(v - hi)
+                    auto split8 = [&](const unsigned char* q, h16x8& hi8, h16x8& lo8) __attribute__((always_inline)) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(q), b1 = *reinterpret_cast<const f32x4*>(q + 256);
+                        const float x[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const f32x2 sc{x[e], x[e + 1]};
+                            const h16x2 h = __builtin_convertvector(sc, h16x2);
+                            const f32x2 rem = sc - __builtin_convertvector(h, f32x2);
+                            const h16x2 l = __builtin_convertvector(rem, h16x2);
+                            hi8[e] = h[0]; hi8[e + 1] = h[1];
+                            lo8[e] = l[0]; lo8[e + 1] = l[1];
+                        }
+                    };
+                    split8(A + fi * 2048, ah0, al0);
+                    split8(A + fi * 2048 + 1024, ah1, al1);
+                } else {
+                    ah0 = *reinterpret_cast<const h16x8*>(A + fi * 2048);
+                    ah1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024);
+                    al0 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 512);
+                    al1 = *reinterpret_cast<const h16x8*>(A + fi * 2048 + 1024 + 512);
+                }
                 wh_static_for<5>([&](auto NN) {
                     constexpr int n = decltype(NN)::value;
                     constexpr int slot = (fi & 1) * 5 + n;
