@@ -124,3 +124,55 @@ def test_wgrad_wide_kernel_reads_lds_with_plain_b64_and_dmas_16_bytes():
     assert re.search(r"Occupancy:\s+4\b", meta)
     scratch = int(re.search(r"ScratchSize:\s+(\d+)", meta).group(1))
     assert scratch <= 64, scratch                  # (a few spilled address registers in the 4-term copies; none holds data)
+
+
+TU_WH = """
+#include "conv_wh.h"
+namespace sinddm {
+ConvProfiler& conv_profiler() { static ConvProfiler p; return p; }
+int touch_wh(const ConvArgs& a, hipStream_t st) { return conv_wh_launch(a, st); }
+int touch_h2(const ConvArgs& a, hipStream_t st) { return conv_h2_launch(a, st); }
+}
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_binary16_kernels_fit_their_register_budget():
+    """conv_wh / conv_h2 run two waves per SIMD (512-thread workgroups): 256 registers per lane, and both sit within a
+    handful of that limit (160 accumulators + operand rings).  A spill would not fail any parity test -- it would put
+    accumulators in scratch memory and cost tens of percent -- so the compiler's own resource summary is checked: no scratch,
+    no VGPR spill, the MFMA counts of the main loops (conv_wh: 4 frequencies x 5 column tiles x 4 = 80 per chunk in the
+    multiplying instantiation, none in the service one's loop; conv_h2<5>: 3 x 5 x 6 = 90 per sub-step)."""
+    from sinddm_amd import build
+    tmp = tempfile.mkdtemp(prefix="whisa")
+    try:
+        src = os.path.join(tmp, "t.hip")
+        with open(src, "w") as f:
+            f.write(TU_WH)
+        flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+        subprocess.check_call([HIPCC, *flags, "-I", os.path.join(ROOT, "include"), "-I", build.CSRC,
+                               "--cuda-device-only", "-S", src, "-o", os.path.join(tmp, "t.s")],
+                              stderr=subprocess.DEVNULL)
+        s = open(os.path.join(tmp, "t.s")).read()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    meta = {}
+    for blk in re.findall(r"- \.agpr_count:.*?\.wavefront_size: +\d+", s, re.S):
+        name = re.search(r"\.name: +(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(r"\.%s: +(\d+)" % k, blk).group(1))
+                      for k in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "max_flat_workgroup_size")}
+    wh = [k for k in meta if "conv_wh_kernel" in k]
+    h2 = [k for k in meta if "conv_h2_kernel" in k]
+    assert len(wh) == 1 and len(h2) == 2, sorted(meta)
+    for k in wh + h2:
+        m = meta[k]
+        assert m["max_flat_workgroup_size"] == 512 and m["vgpr_count"] <= 256, (k, m)
+        # (conv_h2<5>, the A/B reference, keeps a few loop-invariant addresses in scratch outside its main loop)
+        limit = 0 if k in wh else 8
+        assert m["vgpr_spill_count"] <= limit and m["private_segment_fixed_size"] <= 4 * limit, (k, m)
+    body = s[s.index(wh[0] + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    assert body.count("v_mfma_f32_16x16x32_f16") == 80
+    b5 = s[s.index("_ZN6sinddm14conv_h2_kernelILi5EEEvNS_8ConvArgsE:"):]
+    b5 = b5[:b5.index(".Lfunc_end")]
+    assert b5.count("v_mfma_f32_32x32x16_f16") == 90
