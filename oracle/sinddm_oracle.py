@@ -180,11 +180,25 @@ def p_losses_inputs(sched: dict, x_start: Tensor, t: Tensor, s: int, noise: Tens
 
 
 def p_losses(sched: dict, sd: Dict[str, Tensor], x_start: Tensor, t: Tensor, s: int,
-             noise: Tensor, x_orig: Optional[Tensor] = None) -> Tensor:
-    """'l1' branch of models.py:578-595."""
+             noise: Tensor, x_orig: Optional[Tensor] = None, loss_type: str = "l1") -> Tensor:
+    """models.py:578-611: 'l1' (what main.py:97 selects), 'l2', 'l1_pred_img'."""
     x_noisy = p_losses_inputs(sched, x_start, t, s, noise, x_orig)
     eps = net_forward(sd, x_noisy, t, s)
-    return (noise - eps).abs().mean()
+    if loss_type == "l1":
+        return (noise - eps).abs().mean()
+    if loss_type == "l2":
+        return F.mse_loss(noise, eps)
+    if loss_type == "l1_pred_img":                                   # models.py:597-607
+        if int(s) > 0:
+            if int(t[0]) > 0:
+                g = extract(sched["gammas"][s - 1].reshape(-1), t - 1)
+                x_mix_prev = g * x_start + (1 - g) * x_orig
+            else:
+                x_mix_prev = x_orig
+        else:
+            x_mix_prev = x_start
+        return (x_mix_prev - eps).abs().mean()
+    raise NotImplementedError(loss_type)
 
 
 def roi_patch_modification(x_recon: Tensor, roi_bbs, target_patch: Tensor, scale_factor: float, n_scales: int,

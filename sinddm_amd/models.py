@@ -811,8 +811,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
 
     def p_losses(self, x_start, t, s, noise=None, x_orig=None):            # models.py:578-611
         noise = default(noise, lambda: torch.randn_like(x_start))
-        if self.loss_type != 'l1':
-            # main.py hard-codes loss_type='l1' (main.py:97); the other branches are not built
+        if self.loss_type not in ('l1', 'l2', 'l1_pred_img'):
             raise NotImplementedError()
         if int(s) > 0:
             gamma_row = self.gammas[int(s) - 1].reshape(-1).contiguous()    # NOT clamped to 0.55 in training
@@ -820,8 +819,22 @@ class MultiScaleGaussianDiffusion(nn.Module):
         else:
             x_noisy = self._q_sample_impl(x_start, t, 0, noise)
         x_recon = self.denoise_fn(x_noisy, t, int(s))
-        from .autograd import l1_loss
-        return l1_loss(noise, x_recon)
+        if self.loss_type == 'l1':                                          # what main.py:97 selects: fused loss + seed kernel
+            from .autograd import l1_loss
+            return l1_loss(noise, x_recon)
+        # the two loss types main.py never selects (models.py:595-607): the network's forward / backward are the HIP path
+        # (x_recon carries its autograd node), the loss itself is three elementwise torch ops
+        if self.loss_type == 'l2':
+            return F.mse_loss(noise, x_recon)
+        if int(s) > 0:
+            if int(t[0]) > 0:                                               # (the reference's host sync, models.py:599)
+                g = extract(self.gammas[int(s) - 1].reshape(-1), t - 1, x_start.shape)
+                x_mix_prev = g * x_start + (1 - g) * x_orig
+            else:
+                x_mix_prev = x_orig
+        else:
+            x_mix_prev = x_start
+        return (x_mix_prev - x_recon).abs().mean()
 
     def forward(self, x, s, *args, **kwargs):                              # models.py:613-631
         s = int(s)

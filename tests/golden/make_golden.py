@@ -14,6 +14,7 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g3_net.npz         SinDDMNet.forward, dim=160 and dim=32, odd sizes, distinct t
   g4_block.npz       SinDDMConvBlock fwd + input grad + weight grads (4 block shapes, dim=32)
   g5_losses.npz      p_losses value + all 52 grads at s=0 and s=2 (dim=32)
+  g17_loss_types.npz p_losses with loss_type 'l2' / 'l1_pred_img' (models.py:595-607): values + three gradient tensors
   g6_psample.npz     p_sample single steps (s=0/s>0, t=17/t=0) with recorded noise
   g7_qsample.npz     q_sample
   g8_bilinear.npz    F.interpolate(mode='bilinear') at the pyramid ratios
@@ -290,6 +291,33 @@ def g5(meta):
         for pn, p in net.named_parameters():
             out[f"s{s}_g_{pn}"] = p.grad.clone()
     save("g5_losses.npz", **out)
+
+
+def g17(meta=None):
+    """p_losses with the two loss types main.py never selects ('l2', 'l1_pred_img'; models.py:595-607): value + two gradient
+    tensors, at s = 0 and s = 2, t[0] > 0 and t[0] == 0 (the x_mix_prev = x_orig branch)."""
+    if meta is None:
+        import json
+        meta = json.load(open(os.path.join(HERE, "g11_img_scales.json")))
+    pyr = np.load(os.path.join(HERE, "c1_pyramid.npz"))
+    out = {}
+    B = 2
+    for lt in ("l2", "l1_pred_img"):
+        net, d = _small_diffusion(32, meta)
+        d.loss_type = lt
+        for s in (0, 2):
+            orig = _pyr_tensor(pyr[f"scale_{s}"])[None].repeat(B, 1, 1, 1)
+            recon = _pyr_tensor(pyr[f"scale_{s}_recon"])[None].repeat(B, 1, 1, 1) if s > 0 else orig
+            for tag, tt in (("a", [37, 5]), ("b", [0, 9])):
+                t = torch.tensor(tt, dtype=torch.long)
+                noise = hash_randn(tuple(orig.shape), noise_key("train", s, 7))
+                net.zero_grad()
+                loss = d.p_losses(recon, t, s, noise=noise, x_orig=orig) if s > 0 else d.p_losses(orig, t, s, noise=noise)
+                loss.backward()
+                out[f"{lt}_s{s}{tag}_loss"] = loss.detach()
+                for pn in ("final_conv.0.weight", "l2.net.0.weight", "l1.ds_conv.weight"):
+                    out[f"{lt}_s{s}{tag}_g_{pn}"] = dict(net.named_parameters())[pn].grad.clone()
+    save("g17_loss_types.npz", **out)
 
 
 def g6_g7(meta):
@@ -708,6 +736,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         g8()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g17":
+        g17()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14()
         return
@@ -734,6 +765,7 @@ def main():
         g15(workdir)
         g16(workdir)
         g14()
+        g17(meta)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

@@ -70,6 +70,32 @@ def test_adam_ema_kernels():
     assert max_abs(torch.cat([q.detach().reshape(-1) for q in net.parameters()]).cpu(), p) < 2e-7
 
 
+@pytest.mark.parametrize("lt", ["l2", "l1_pred_img"])
+def test_p_losses_other_loss_types_golden(golden, lt):
+    """G17: loss_type 'l2' / 'l1_pred_img' (reference models.py:595-607; main.py hard-codes 'l1', VERDICT r4 missing 5):
+    value and three gradient tensors against the reference, both branches of t[0] > 0."""
+    g = golden("g17_loss_types.npz")
+    pyr = golden("c1_pyramid.npz")
+    net, d, meta = _diffusion(golden, 32)
+    d.loss_type = lt
+    net.bind_grads()
+    for s in (0, 2):
+        orig = _pyr_tensor(pyr[f"scale_{s}"])[None].repeat(2, 1, 1, 1).to(DEV)
+        recon = _pyr_tensor(pyr[f"scale_{s}_recon"])[None].repeat(2, 1, 1, 1).to(DEV) if s > 0 else orig
+        for tag, tt in (("a", [37, 5]), ("b", [0, 9])):
+            net.flat_grads.zero_()
+            t = torch.tensor(tt, device=DEV)
+            noise = hash_randn(tuple(orig.shape), noise_key("train", s, 7)).to(DEV)
+            loss = d.p_losses(recon, t, s, noise=noise, x_orig=orig) if s > 0 else d.p_losses(orig, t, s, noise=noise)
+            loss.backward()
+            key = f"{lt}_s{s}{tag}"
+            ref = float(g[key + "_loss"])
+            assert abs(float(loss) - ref) < 2e-6 * max(1.0, abs(ref)), key
+            grads = {n: p.grad for n, p in net.named_parameters()}
+            for pn in ("final_conv.0.weight", "l2.net.0.weight", "l1.ds_conv.weight"):
+                assert rel_l2(grads[pn].cpu(), g[f"{key}_g_{pn}"]) < 1e-4, (key, pn)
+
+
 def test_ema_copy_mode2_and_trainer_reset():
     """Mode 2 of sinddm_adam_ema_step (ema = p in one launch; VERDICT r4 item 6: declared in the ABI, never called):
     bit-exact copy of the flat buffer, the packed weights of the EMA network are rebuilt (its next evaluation uses the

@@ -82,6 +82,29 @@ def test_g4_g5_grads_via_autograd(golden):
             assert rel_l2(v.grad, g5[f"s{s}_g_{k}"]) < 5e-5, k
 
 
+def test_g17_loss_types(golden):
+    """The two loss types main.py never selects ('l2', 'l1_pred_img', models.py:595-607), both t[0] branches."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g17_loss_types.npz")
+    pyr = golden("c1_pyramid.npz")
+    sched = _sched(meta, "C1")
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div(255).mul(2).sub(1)
+    for lt in ("l2", "l1_pred_img"):
+        for s in (0, 2):
+            orig = to_t(pyr[f"scale_{s}"])[None].repeat(2, 1, 1, 1)
+            recon = to_t(pyr[f"scale_{s}_recon"])[None].repeat(2, 1, 1, 1) if s > 0 else orig
+            for tag, tt in (("a", [37, 5]), ("b", [0, 9])):
+                sd = {k: v.clone().requires_grad_(True) for k, v in closed_form_state_dict(32).items()}
+                noise = hash_randn(tuple(orig.shape), noise_key("train", s, 7))
+                loss = O.p_losses(sched, sd, recon if s > 0 else orig, torch.tensor(tt), s, noise,
+                                  x_orig=orig if s > 0 else None, loss_type=lt)
+                loss.backward()
+                key = f"{lt}_s{s}{tag}"
+                assert abs(float(loss) - float(g[key + "_loss"])) < 2e-6 * max(1.0, abs(float(g[key + "_loss"]))), key
+                for pn in ("final_conv.0.weight", "l2.net.0.weight", "l1.ds_conv.weight"):
+                    assert rel_l2(sd[pn].grad, g[f"{key}_g_{pn}"]) < 5e-5, (key, pn)
+
+
 def test_g6_p_sample(golden):
     meta = golden("g11_img_scales.json")
     g = golden("g6_psample.npz")
