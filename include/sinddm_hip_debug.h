@@ -43,6 +43,11 @@ int sinddm_debug_conv_path(int dim, int B, int H, int W);
  * else the value sinddm_debug_conv_path gives for the padded shape. */
 int sinddm_debug_infer_path(int dim, int B, int H, int W);
 
+/* ... and for TRAINING launches (sinddm_net_forward_train / sinddm_net_backward: plain rows, no padding): 8 = the forward
+ * 3x3 convs and both data-gradient convs of the dim -> dim blocks take conv_wh (same rule as inference; needs W % 4 == 0),
+ * else the value of sinddm_debug_conv_path.  The weight gradients stay on the fp32 pipe either way. */
+int sinddm_debug_train_path(int dim, int B, int H, int W);
+
 /* Process-global switch of the binary16 hi/lo 3x3 kernels: bit 0 = conv_h2.h (direct implicit GEMM; 7 from
  * sinddm_debug_infer_path), bit 1 = conv_wh.h (Winograd F(2x4) with binary16 frequency GEMMs; 8, preferred where both
  * apply).  0 keeps the launches that qualify on the fp32-MFMA Winograd kernels; the default is 3.  Returns the previous value.

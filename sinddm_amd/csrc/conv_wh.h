@@ -159,9 +159,11 @@ __global__ __launch_bounds__(256) void wh_pack_kernel(const float* __restrict__ 
     const double sc = m < M ? 1.0 / (double)wsinv[m] : 1.0;
 #pragma unroll
     for (int f = 0; f < 24; ++f) {
-        const float s = (float)(u[f] * sc);                       // (rounded once to fp32: what an fp32 kernel would hold)
-        const _Float16 hi = (_Float16)s;
-        const _Float16 lo = (_Float16)(s - (float)hi);
+        // split the float64 value itself (no fp32 rounding in between: the two pieces then carry U to ~2^-23.5 rms, against 2^-23
+        // through fp32 -- the weights' representation error is coherent over all pixels, see the note on `sg` in the kernel)
+        const double s = u[f] * sc;
+        const _Float16 hi = (_Float16)(float)s;
+        const _Float16 lo = (_Float16)(float)(s - (double)(float)hi);
         const long long o = ((((long long)(cb * nch + ch) * 24 + f) * 5 + n) * 2) * 256 + (kh * 16 + co16) * 8 + e;
         img[o] = hi;
         img[o + 256] = lo;
@@ -302,7 +304,13 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
         const int cb = cur.cb, b = cur.b, y0 = cur.y0, x0 = cur.x0;
 
         const int xs = p.amax_in ? wh_shift_for(p.amax_in[(size_t)b * AMAX_STRIDE], WH_TARGET_EXP) : 0;
-        const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
+        // Sign dither: v_mfma_f32_16x16x32_f16 rounds its sum with a small bias toward -infinity whatever the signs (measured,
+        // tools/ubench/mfma_bias.hip: -0.008 ulp of the accumulator per instruction, 1.4 % of the rms rounding error).  Invisible per
+        // element, but coherent over a plane: a sum over 46 000 pixels amplifies it 215-fold against the white part (the bias
+        // and condition-path gradients of training are such sums).  Items of neighbouring tiles therefore run with opposite
+        // signs of V (folded into the exact power-of-two scales): the bias alternates in the image and cancels in the sums.
+        const float sg = (((x0 >> 5) + (y0 >> 3) + b) & 1) ? -1.0f : 1.0f;
+        const float sx = sg * h2_pow2(xs), inv_sx = sg * h2_pow2(-xs);
         const f32x2 sx2{sx, sx};
 
         const __amdgpu_buffer_rsrc_t rsin = in_rsrc(b);

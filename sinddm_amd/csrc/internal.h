@@ -35,6 +35,8 @@ struct TrainBufs {
     float* dcond;   // [B][cond_stride]
     float* small;   // cond-path backward scratch  [B][4*32 + 32 + 128]
     float* wscr;    // [dim][9][dim] staging slab of the 3x3 weight-gradient kernel
+    float* amax;    // [2][B][AMAX_STRIDE] running-max scalars of the binary16 3x3 kernels' inputs: forward (slot 2l + i, as
+                    // in inference), backward (slot 2l: gradient of block l's output, 2l + 1: gradient of its conv1 output)
 };
 
 struct ChainStep;   // sampler-run extras (sinddm_fwd.hip)
@@ -49,6 +51,15 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
 // which kernel generation a dim -> dim 3x3 conv launch of this shape takes: 4 / 3 = F(2x4) conv_wino4 / conv_wino3,
 // 2 = F(2x2) conv_wino2 / conv_wino, 0 = direct implicit GEMM
 int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W);
+
+// conv_wh.h (the Winograd F(2x4) kernel with binary16 hi/lo frequency GEMMs) lives in sinddm_fwd.hip; the backward TU
+// reaches it through these: the dispatch rule, one launch, the weight image of a conv (transpose = 1: of its data gradient)
+struct ConvArgs;
+bool wh_applies(int B, int H, int W, int cin, int cout);
+int wh_conv(const ConvArgs& c, hipStream_t st);
+int wh_pack(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st);
+// max |x| of every sample of x[B][per_sample] (per_sample % 4 == 0) into amax[b * AMAX_STRIDE] (zeroed by the caller)
+int amax_tensor_launch(const float* x, float* amax, int B, long long per_sample, hipStream_t st);
 
 int dwconv_launch(const float* x, const float* w, const float* bias, const float* cond, int cond_stride,
                   const float* addt, int flip, float* out, int B, int C, int H, int W, hipStream_t st, int pi = 0, int po = 0,

@@ -887,6 +887,8 @@ struct BwdPack {
     long long dg2[4], dg1[4], dres[4], dfin, zero;
     long long wdg2[4], wdg1[4];     // Winograd images of the 3x3 data-gradient convs (wdg1 = -1: stays direct)
     long long wdg2f[4], wdg1f[4];   // their F(2x4) images (conv_wino3.h), -1 = shape not supported
+    long long qdg2[4], qdg1[4];     // their binary16 hi/lo F(2x4) images (conv_wh.h), -1 = shape not supported
+    long long qs2[4], qs1[4];       // ... and the per-output-channel scales of those
     long long total;
     int mt2[4], mt1[4], cb2[4], cb1[4];
     int mtf, cbf;
@@ -921,6 +923,19 @@ static BwdPack make_bwd_pack(const NetPlan& P) {
         const bool kok = b.cout % 16 == 0;
         if (kok && k.mt2[l] == 5 && b.cout % 80 == 0) { k.wdg2f[l] = q; q += (long long)k.cb2[l] * nchW * 32768; } else k.wdg2f[l] = -1;
         if (kok && k.mt1[l] == 5 && b.cin % 80 == 0) { k.wdg1f[l] = q; q += (long long)k.cb1[l] * nchW * 32768; } else k.wdg1f[l] = -1;
+    }
+    // binary16 hi/lo images of the same convs (conv_wh.h): K = forward cout in 16-channel chunks, 80-channel row blocks
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        q = (q + 63) / 64 * 64;
+        if (wh_plan_ok(b.cout, b.cout)) {
+            k.qdg2[l] = q; q += wh_plan_halfs(b.cout, b.cout) / 2;
+            k.qs2[l] = q; q += (b.cout + 63) / 64 * 64;
+        } else k.qdg2[l] = k.qs2[l] = -1;
+        if (wh_plan_ok(b.cout, b.cin)) {
+            k.qdg1[l] = q; q += wh_plan_halfs(b.cout, b.cin) / 2;
+            k.qs1[l] = q; q += (b.cin + 63) / 64 * 64;
+        } else k.qdg1[l] = k.qs1[l] = -1;
     }
     k.zero = q; q += 64;
     k.total = q;
@@ -989,10 +1004,24 @@ static int pack_backward(const NetPlan& P, const float* params, float* packed, h
         if (k.wdg2f[l] >= 0) addf(k.wdg2f[l], b.c2_w, b.cout, b.cout, k.cb2[l]);
         if (k.wdg1f[l] >= 0) addf(k.wdg1f[l], b.c1_w, b.cin, b.cout, k.cb1[l]);
     }
-    if (n == 0) return 0;
-    f.nseg = n;
-    f.total = total;
-    return pack_launch(params, packed, f, st);
+    if (n > 0) {
+        f.nseg = n;
+        f.total = total;
+        rc = pack_launch(params, packed, f, st);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < 4; ++l) {
+        const BlockPlan& b = P.blk[l];
+        if (k.qdg2[l] >= 0) {
+            rc = wh_pack(params + b.c2_w, packed + k.qs2[l], packed + k.qdg2[l], b.cout, b.cout, 1, st);
+            if (rc) return rc;
+        }
+        if (k.qdg1[l] >= 0) {
+            rc = wh_pack(params + b.c1_w, packed + k.qs1[l], packed + k.qdg1[l], b.cin, b.cout, 1, st);
+            if (rc) return rc;
+        }
+    }
+    return 0;
 }
 
 // =====================================================================================
@@ -1024,6 +1053,7 @@ static size_t carve_train(const NetPlan& P, int B, int H, int W, char* base, Tra
     t.dcond = take((size_t)B * P.cond_stride);
     t.small = take((size_t)B * (128 + 32 + 128));
     t.wscr = take((size_t)P.dim * P.dim * 9);
+    t.amax = take((size_t)2 * B * AMAX_STRIDE);
     if (tb) *tb = t;
     return off;
 }
@@ -1063,11 +1093,20 @@ static int conv3x3_wino(const float* zero, const float* in3, int cin3, const flo
 // the per-sample condition gradient goes to tb.dcond, the input gradient to `dst` (skipped when null).  dU / dH: scratch.
 static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float* params, const float* packed_bwd,
                           const float* xin, float* dO, float* dU, float* dH, float* dst, float* grads, const TrainBufs& tb,
-                          int B, int H, int W, hipStream_t st) {
+                          int B, int H, int W, hipStream_t st, float* amax_b = nullptr, bool dO_published = false) {
     const BlockPlan& b = P.blk[l];
     const float* zp = packed_bwd + k.zero;
     int rc;
     const int nchK = (b.cout + KC - 1) / KC;
+    // the two 3x3 data-gradient convs on the binary16 hi/lo Winograd kernel (conv_wh.h) where its rule takes the launch;
+    // `amax_b` = the backward half of tb.amax (zeroed by the caller): slot 2l = max |dO| per sample (maintained by the kernel
+    // that wrote dO when `dO_published`), slot 2l + 1 = max |dU| (by the first conv's epilogue)
+    const bool wh2 = amax_b && wino_enabled() && k.qdg2[l] >= 0 && wh_applies(B, H, W, b.cout, b.cout);
+    const bool wh1 = wh2 && k.qdg1[l] >= 0 && wh_applies(B, H, W, b.cout, b.cin);
+    if (wh2 && !dO_published) {
+        rc = amax_tensor_launch(dO, amax_b + 2 * l, B, (long long)b.cout * H * W, st);
+        if (rc) return rc;
+    }
     // conv2 + residual projection weight grads
     rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr);
     if (rc) return rc;
@@ -1076,7 +1115,13 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
         if (rc) return rc;
     }
     // dU = dgrad_conv2(dO) * GELU'(u)
-    if (wino_enabled() && b.cout % 4 == 0)        // (K of both data-gradient convs = cout; % 4: see conv_wino_launch)
+    if (wh2) {
+        ConvArgs c{};
+        c.zero = zp; c.in = dO; c.Cin = b.cout; c.w3 = packed_bwd + k.qdg2[l]; c.wsinv = packed_bwd + k.qs2[l];
+        c.amax_in = amax_b + 2 * l; c.amax_out = wh1 ? amax_b + 2 * l + 1 : nullptr;
+        c.aux = tb.u[l]; c.act = 2; c.out = dU; c.Cout = b.cout; c.B = B; c.H = H; c.W = W;
+        rc = wh_conv(c, st);
+    } else if (wino_enabled() && b.cout % 4 == 0)        // (K of both data-gradient convs = cout; % 4: see conv_wino_launch)
         rc = conv3x3_wino(zp, dO, b.cout, packed_bwd + k.wdg2[l], k.wdg2f[l] >= 0 ? packed_bwd + k.wdg2f[l] : nullptr, tb.u[l], 2,
                           dU, b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
     else
@@ -1086,7 +1131,13 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
     // conv1 weight grads, dH = dgrad_conv1(dU)
     rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
     if (rc) return rc;
-    if (wino_enabled() && k.wdg1[l] >= 0 && b.cout % 4 == 0)
+    if (wh1) {
+        ConvArgs c{};
+        c.zero = zp; c.in = dU; c.Cin = b.cout; c.w3 = packed_bwd + k.qdg1[l]; c.wsinv = packed_bwd + k.qs1[l];
+        c.amax_in = amax_b + 2 * l + 1;
+        c.act = 0; c.out = dH; c.Cout = b.cin; c.B = B; c.H = H; c.W = W;
+        rc = wh_conv(c, st);
+    } else if (wino_enabled() && k.wdg1[l] >= 0 && b.cout % 4 == 0)
         rc = conv3x3_wino(zp, dU, b.cout, packed_bwd + k.wdg1[l], k.wdg1f[l] >= 0 ? packed_bwd + k.wdg1f[l] : nullptr, nullptr, 0,
                           dH, b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
     else
@@ -1106,7 +1157,10 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
             if (rc) return rc;
             radd = dU;
         }
-        rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st);
+        // (dst is the next block's dO: its running max comes out of this launch when that block's convs will want it)
+        float* pub = nullptr;
+        if (amax_b && l > 0 && wino_enabled() && k.qdg2[l - 1] >= 0 && wh_applies(B, H, W, b.cin, b.cin)) pub = amax_b + 2 * (l - 1);
+        rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st, 0, 0, pub);
         if (rc) return rc;
     }
     return 0;
@@ -1122,6 +1176,8 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
     rc = wgrad_launch(zp, grad_out, tb.o[3], grads + P.fin_w, grads + P.fin_b, B, H, W, P.half, CHANNELS, 1, st);
     if (rc) return rc;
     int di = 0;   // index of the scratch buffer holding dOut of the current block
+    float* amax_b = tb.amax + (size_t)B * AMAX_STRIDE;
+    if (hipMemsetAsync(amax_b, 0, (size_t)B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
     rc = conv1x1_or_3x3(zp, nullptr, 0, nullptr, 0, grad_out, CHANNELS, packed_bwd + k.dfin, 1, nullptr, 0, tb.s[di],
                         P.half, k.mtf, k.cbf, B, H, W, st);
     if (rc) return rc;
@@ -1132,7 +1188,8 @@ static int net_backward_impl(const NetPlan& P, const float* params, const float*
         float* dH = tb.s[(di + 2) & 3];
         float* dX = tb.s[(di + 3) & 3];
         float* dst = (l == 0) ? grad_x : dX;
-        rc = block_backward(P, k, l, params, packed_bwd, xin, dO, dU, dH, (l > 0 || grad_x) ? dst : nullptr, grads, tb, B, H, W, st);
+        rc = block_backward(P, k, l, params, packed_bwd, xin, dO, dU, dH, (l > 0 || grad_x) ? dst : nullptr, grads, tb, B, H, W, st,
+                            amax_b, l < 3);
         if (rc) return rc;
         if (l > 0 || grad_x) di = (di + 3) & 3;
     }
@@ -1238,6 +1295,14 @@ int sinddm_debug_conv_path(int dim, int B, int H, int W) {
     return conv3x3_path(b.cout, b.cout, b.coblks, B, H, W);
 }
 
+int sinddm_debug_train_path(int dim, int B, int H, int W) {
+    NetPlan p = make_plan(dim);
+    if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
+    const BlockPlan& b = p.blk[2];
+    if (wino_enabled() && b.pk_q2 >= 0 && wh_applies(B, H, W, b.cout, b.cout)) return 8;
+    return conv3x3_path(b.cout, b.cout, b.coblks, B, H, W);
+}
+
 int sinddm_debug_block_train(const float* params, const float* packed, const float* packed_bwd, int dim, int l,
                              const float* x, const float* cond_bias, const float* grad_y, float* y, float* grad_x,
                              float* grad_params, float* dcond, int B, int H, int W, void* ws, size_t ws_bytes,
@@ -1252,14 +1317,17 @@ int sinddm_debug_block_train(const float* params, const float* packed, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     const BlockPlan& b = p.blk[l];
     const size_t HW = (size_t)H * W;
-    int rc = block_forward(p, l, params, packed, x, cond_bias, b.cin, tb.h[l], tb.g[l], tb.o[l], tb.u[l], B, H, W, st);
+    if (hipMemsetAsync(tb.amax, 0, (size_t)2 * B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
+    int rc = block_forward(p, l, params, packed, x, cond_bias, b.cin, tb.h[l], tb.g[l], tb.o[l], tb.u[l], B, H, W, st, 0,
+                           tb.amax + 2 * l);
     if (rc) return rc;
     if (hipMemcpyAsync(y, tb.o[l], B * b.cout * HW * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SINDDM_E_BADARG;
     if (hipMemcpyAsync(tb.s[0], grad_y, B * b.cout * HW * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return SINDDM_E_BADARG;
     const BwdPack k = make_bwd_pack(p);
-    rc = block_backward(p, k, l, params, packed_bwd, x, tb.s[0], tb.s[1], tb.s[2], grad_x, grad_params, tb, B, H, W, st);
+    rc = block_backward(p, k, l, params, packed_bwd, x, tb.s[0], tb.s[1], tb.s[2], grad_x, grad_params, tb, B, H, W, st,
+                        tb.amax + (size_t)B * AMAX_STRIDE, false);
     if (rc) return rc;
     if (hipMemcpy2DAsync(dcond, b.cin * sizeof(float), tb.dcond + b.cond_off, p.cond_stride * sizeof(float),
                          b.cin * sizeof(float), B, hipMemcpyDeviceToDevice, st) != hipSuccess)

@@ -1152,14 +1152,43 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     return rc;
 }
 
+bool wh_applies(int B, int H, int W, int cin, int cout) { return conv_wh_applies(B, H, W, cin, cout); }
+int wh_conv(const ConvArgs& c, hipStream_t st) { return conv_wh_launch(c, st); }
+int wh_pack(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st) {
+    return wh_pack_launch(w, wsinv, img, cin, cout, transpose, st);
+}
+
+__global__ __launch_bounds__(256) void amax_tensor_kernel(const float* __restrict__ x, float* __restrict__ amax, long long n4) {
+    const int b = blockIdx.y;
+    const f32x4* p = reinterpret_cast<const f32x4*>(x) + (size_t)b * n4;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = p[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    amax_publish(m, amax + (size_t)b * AMAX_STRIDE);
+}
+int amax_tensor_launch(const float* x, float* amax, int B, long long per_sample, hipStream_t st) {
+    if (per_sample % 4 != 0) return SINDDM_E_BADSHAPE;
+    const long long n4 = per_sample / 4;
+    long long bx = (n4 + 2047) / 2048;                    // eight 16-byte loads per lane
+    const long long cap = (8LL * wino2_cu_count() + B - 1) / B;
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(amax_tensor_kernel, dim3((unsigned)bx, B), dim3(256), 0, st, x, amax, n4);
+    SINDDM_LAUNCH_CHECK();
+    return 0;
+}
+
 int net_forward_impl(const NetPlan& P, const float* params, const float* packed, const float* x, const int64_t* t_dev,
                      int t_host, float scale, float* out, int B, int H, int W, void* ws, size_t ws_bytes,
                      hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
     FwdBuffers fb{};
     float* xpad = nullptr;
-    float* amax = nullptr;       // eight running-max scalars (conv_h2.h); inference only
+    float* amax = nullptr;       // eight running-max scalars per sample (conv_h2.h)
     if (tb) {
         fb.cond = tb->cond;
+        amax = tb->amax;
     } else {
         if (ws_bytes < fwd_workspace_core(P, B, H, W)) return SINDDM_E_WORKSPACE;
         char* base = static_cast<char*>(ws);
@@ -1192,8 +1221,17 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         SINDDM_LAUNCH_CHECK();
     }
 
-    if (amax && SINDDM_CONV_H2) {
-        if (hipMemsetAsync(amax, 0, (size_t)B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
+    if (amax) {
+        // the running-max scalars exist for the binary16 kernels: a launch shape none of them takes (coarse pyramid scales)
+        // neither maintains nor zeroes them
+        bool any = false;
+        for (int l = 0; l < 4; ++l) {
+            const BlockPlan& b = P.blk[l];
+            any = any || (b.pk_q1 >= 0 && conv_wh_applies(B, H, Wp, b.cin, b.cout)) || (b.pk_q2 >= 0 && conv_wh_applies(B, H, Wp, b.cout, b.cout)) ||
+                  (b.pk_h1 >= 0 && conv_h2_applies(B, H, Wp, b.cin, b.cout)) || (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout));
+        }
+        if (!any) amax = nullptr;
+        else if (hipMemsetAsync(amax, 0, (size_t)B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
     }
     const float* cur = x;
     if (padded) {

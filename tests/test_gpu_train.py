@@ -303,6 +303,71 @@ def test_net_backward_full_size_vs_oracle_autograd():
     print("full-size backward: worst rel-L2 gradient error vs float64 (HIP, CPU fp32)", worst, cpu_worst)
 
 
+def test_net_backward_binary16_convs_vs_float64():
+    """A training launch big enough for the binary16 hi/lo Winograd kernel (conv_wh.h: 8 x 186x248 = 12 items per CU):
+    the forward 3x3 convs and both data-gradient convs of every block run on it (sinddm_debug_train_path = 8), fed by the
+    per-sample running-max scalars of the training workspace (backward half: maintained by the depthwise data-gradient
+    launches, the first conv's epilogue and one standalone pass over the final conv's data gradient).
+
+    Gate, as for inference (tests/test_gpu_h2.py): against the FLOAT64 oracle autograd the binary16 path may not be worse than
+    1.5x the fp32-MFMA path of the same library on the same inputs (per class of tensors, floor 5e-5: the condition path's
+    sums over all pixels carry run-to-run atomics noise)."""
+    from sinddm_amd import _lib
+    from sinddm_amd.models import SinDDMNet
+    lib = _lib.load()
+    dim, B, H, W = 160, 8, 186, 248
+    x = hash_randn((B, 3, H, W), 25)
+    gy = hash_randn((B, 3, H, W), 26) / (B * 3 * H * W)
+    t = torch.tensor([731, 12, 5, 999, 340, 77, 501, 888])
+
+    def run(mode):
+        prev = lib.sinddm_debug_set_h2(mode)
+        try:
+            assert lib.sinddm_debug_train_path(dim, B, H, W) == (8 if mode == 3 else 4)
+            net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+            net.load_state_dict(closed_form_state_dict(dim))
+            net.bind_grads()
+            net.flat_grads.zero_()
+            xd = x.to(DEV).requires_grad_(True)
+            y = net(xd, t.to(DEV), scale=4)
+            y.backward(gy.to(DEV))
+            torch.cuda.synchronize()
+            return (y.detach().cpu().double(), xd.grad.cpu().double(),
+                    {n: p.grad.cpu().double().clone() for n, p in net.named_parameters()})
+        finally:
+            lib.sinddm_debug_set_h2(prev)
+
+    y_h, gx_h, g_h = run(3)
+    y_f, gx_f, g_f = run(0)
+    torch.set_default_dtype(torch.float64)
+    try:
+        sd = {k: v.double().clone().requires_grad_(True) for k, v in closed_form_state_dict(dim).items()}
+        xc = x.double().clone().requires_grad_(True)
+        yc = O.net_forward(sd, xc, t, 4)
+        yc.backward(gy.double())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    y64, gx64, g64 = yc.detach(), xc.grad, {k: v.grad for k, v in sd.items()}
+    e_y = (rel_l2(y_h, y64), rel_l2(y_f, y64))
+    e_gx = (rel_l2(gx_h, gx64), rel_l2(gx_f, gx64))
+    assert e_y[0] < 2e-6 and e_y[0] < 1.5 * e_y[1] + 1e-7, e_y
+    assert e_gx[0] < 2e-5 and e_gx[0] < 1.5 * e_gx[1] + 1e-7, e_gx
+    assert rel_l2(gx_h, gx_f) > 0                      # (the two paths are different kernels)
+
+    def klass(name):
+        if ".mlp." in name or "time_mlp" in name or "time_reshape" in name or name.endswith("ds_conv.bias"):
+            return "cond_path"
+        return "weight" if name.endswith("weight") else "bias"
+    errs = {n: (rel_l2(g_h[n], g64[n]), rel_l2(g_f[n], g64[n])) for n in g_h}
+    worst_f = {}
+    for n, (eh, ef) in errs.items():
+        worst_f[klass(n)] = max(worst_f.get(klass(n), 0.0), ef)
+    for n, (eh, ef) in errs.items():
+        assert eh < max(5e-5, 1.5 * worst_f[klass(n)]), (n, eh, ef, worst_f)
+    print("binary16 training convs vs float64: y", e_y, "grad_x", e_gx, "worst tensor",
+          max(errs.items(), key=lambda kv: kv[1][0]), "fp32-path class worst", worst_f)
+
+
 def test_weight_gradients_reproducible_run_to_run():
     """Regression test of the LDS-DMA publication race: the same backward three times -- the only
     legitimate run-to-run difference is the order of the fp32 atomics (<= 1e-6 rel-L2); the race showed as 1e-4 .. 2e-3 in
