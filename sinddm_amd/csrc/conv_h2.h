@@ -176,7 +176,9 @@ __global__ __launch_bounds__(512) void conv_h2_kernel(ConvArgs p) {
         const int y0 = tyi * H2_TH, x0 = txi * H2_TW;
         // activation scale of this sample
         const int xs = p.amax_in ? h2_shift_for(p.amax_in[(size_t)b * AMAX_STRIDE]) : 0;
-        const float sx = h2_pow2(xs), inv_sx = h2_pow2(-xs);
+        // sign dither (conv_wh.h explains: the binary16 MFMA's rounding bias alternates between neighbouring items)
+        const float sg = ((txi + tyi + b) & 1) ? -1.0f : 1.0f;
+        const float sx = sg * h2_pow2(xs), inv_sx = sg * h2_pow2(-xs);
 
         // staging map (the same for every chunk): task -> byte offset inside the chunk's planes (buffer load: an
         // out-of-range offset reads as zero -- image border, no branch), LDS byte offset

@@ -22,6 +22,16 @@ __global__ void k(const _Float16* A, const _Float16* B, const float* C, float* D
     for (int i = 0; i < 4; ++i) D[(t * 16 + 4 * kg + i) * 16 + r] = acc[i];
 }
 
+// the fp32 pipe for comparison: v_mfma_f32_16x16x4_f32, A[t][16][4], B[t][16][4] (lane: row lane & 15, k = lane >> 4)
+__global__ void k32(const float* A, const float* B, const float* C, float* D) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int r = lane & 15, kg = lane >> 4;
+    f4 acc;
+    for (int i = 0; i < 4; ++i) acc[i] = C[(t * 16 + 4 * kg + i) * 16 + r];
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(t * 16 + r) * 4 + kg], B[(t * 16 + r) * 4 + kg], acc, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) D[(t * 16 + 4 * kg + i) * 16 + r] = acc[i];
+}
+
 static double rnd() { return (double)rand() / RAND_MAX; }
 static double gauss() { return std::sqrt(-2 * std::log(rnd() + 1e-300)) * std::cos(6.283185307179586 * rnd()); }
 
@@ -71,6 +81,34 @@ int main() {
                 }
         printf("%-75s mfma: mean %+8.4f  (x sign(result): %+8.4f)  rms %7.4f ulp   | ideal RN: mean %+8.4f rms %7.4f\n", names[sc], m / n, msgn / n,
                std::sqrt(m2 / n), mrn / n, std::sqrt(m2rn / n));
+    }
+    // fp32 pipe: 4 products of fp32 operands (24 x 24 bits: not exact in fp32) + C
+    {
+        std::vector<float> A32(T * 64), B32(T * 64);
+        float *dA32, *dB32;
+        (void)hipMalloc(&dA32, A32.size() * 4); (void)hipMalloc(&dB32, B32.size() * 4);
+        for (int sc = 0; sc < 3; ++sc) {
+            for (size_t i = 0; i < A32.size(); ++i) { A32[i] = (float)(gauss() * 37.0); B32[i] = (float)(gauss() * 51.0); }
+            const double sig = 37.0 * 51.0 * 2.0;
+            for (size_t i = 0; i < C.size(); ++i) C[i] = (float)(sc == 0 ? gauss() * 8 * sig : (sc == 1 ? 1 : -1) * 8 * sig * (1 + 0.3 * rnd()));
+            (void)hipMemcpy(dA32, A32.data(), A32.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(dB32, B32.data(), B32.size() * 4, hipMemcpyHostToDevice);
+            (void)hipMemcpy(dC, C.data(), C.size() * 4, hipMemcpyHostToDevice);
+            hipLaunchKernelGGL(k32, dim3(T), dim3(64), 0, 0, dA32, dB32, dC, dD);
+            (void)hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost);
+            double m = 0, m2 = 0; long n = 0;
+            for (int t = 0; t < T; ++t)
+                for (int i = 0; i < 16; ++i)
+                    for (int j = 0; j < 16; ++j) {
+                        long double ex = C[t * 256 + i * 16 + j];
+                        for (int q = 0; q < 4; ++q) ex += (long double)A32[(t * 16 + i) * 4 + q] * (long double)B32[(t * 16 + j) * 4 + q];
+                        const float rn = (float)ex;
+                        int e; std::frexp(std::fabs((double)rn) > 0 ? (double)rn : 1.0, &e);
+                        const double ulp = std::ldexp(1.0, e - 24);
+                        const double err = (double)(((long double)D[t * 256 + i * 16 + j] - ex) / ulp);
+                        m += err; m2 += err * err; ++n;
+                    }
+            printf("v_mfma_f32_16x16x4_f32, C %-50s mean %+8.4f  rms %7.4f ulp\n", sc == 0 ? "~ N(0, 8 sigma)" : (sc == 1 ? "~ +8 sigma" : "~ -8 sigma"), m / n, std::sqrt(m2 / n));
+        }
     }
     return 0;
 }
