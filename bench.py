@@ -502,6 +502,7 @@ def train_leg(ctx, steps=5, warmup=2):
     one()
     torch.cuda.synchronize()
     wg_ms, wg_n, wg_fl, wg_ex = _prof(lib, 4, 0)
+    wg_by_gen = {q: _prof(lib, q, 0) for q in (48, 40)}
     mix = {}
     for gen, name in ((8, "conv_wh_kernel"), (7, "conv_h2_kernel"), (4, "conv_wino4_kernel"), (3, "conv_wino3_kernel"),
                       (2, "conv_wino2_kernel"), (1, "conv_wino_kernel")):
@@ -520,13 +521,21 @@ def train_leg(ctx, steps=5, warmup=2):
            "loss_finite": bool(torch.isfinite(loss)),
            "train_path": int(lib.sinddm_debug_train_path(160, 32, H, W))}
     if wg_n:
-        ex = wg_ex / (wg_ms * 1e-3) / 1e12
+        # Winograd-domain 3x3 weight gradients: on the binary16 pipe (wgrad_wh_kernel, generation 8: operands transformed and
+        # split in the kernel, four MFMA terms) where the operands' running maxima exist, fp32 MFMA otherwise
+        wmix = {}
+        for q, name, peak in ((48, "wgrad_wh_kernel", F16_MFMA_PEAK_TFLOPS), (40, "wgrad_wino_kernel", FP32_MFMA_PEAK_TFLOPS)):
+            g_ms, g_n, g_fl, g_ex = wg_by_gen[q]
+            if g_n:
+                wmix[name] = {"launches": int(g_n), "ms_per_step": round(g_ms, 3), "achieved": round(g_ex / (g_ms * 1e-3) / 1e12, 2),
+                              "peak": peak, "frac": round(g_ex / (g_ms * 1e-3) / 1e12 / peak, 4),
+                              "algorithmic_tflops": round(g_fl / (g_ms * 1e-3) / 1e12, 1)}
+        dom = max(wmix.items(), key=lambda kv: kv[1]["ms_per_step"])
         rec["wgrad_roofline"] = {
-            "kernel": "wgrad_wino_kernel", "bound": "mfma", "launches_per_step": wg_n,
+            "kernel": dom[0], "bound": "mfma", "launches_per_step": wg_n,
             "ms_per_step": round(wg_ms, 3), "share_of_step": round(wg_ms / (dt * 1e3), 4),
-            "achieved": round(ex, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ex / FP32_MFMA_PEAK_TFLOPS, 4),
-            "algorithmic_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1)}
+            "achieved": dom[1]["achieved"], "peak": dom[1]["peak"], "unit": "TFLOP/s", "frac": dom[1]["frac"],
+            "algorithmic_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1), "kernel_mix": wmix}
     if cv_n:
         # forward 3x3 convs + both data gradients: on the binary16 hi/lo Winograd kernel where its rule takes the launch
         # (train_path 8), fp32-MFMA Winograd otherwise; executed FLOPs are priced per kernel against ITS pipe's peak

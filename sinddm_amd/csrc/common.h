@@ -30,6 +30,9 @@ namespace sinddm {
 #ifndef SINDDM_WGRAD_WINO     // 1: Winograd-domain 3x3 weight gradient
 #define SINDDM_WGRAD_WINO 1
 #endif
+#ifndef SINDDM_WGRAD_WH       // 1: ... and on the binary16 matrix pipe (wgrad_wh.h) when the operands' running maxima exist (training on conv_wh)
+#define SINDDM_WGRAD_WH 1
+#endif
 #ifndef SINDDM_WGRAD_WIDE     // 1: W % 4 == 0 launches of the Winograd weight gradient on wgrad_wino_wide_kernel (16-byte DMA)
 #define SINDDM_WGRAD_WIDE 1
 #endif

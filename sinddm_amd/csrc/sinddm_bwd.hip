@@ -8,6 +8,7 @@
 #include "conv_wino4.h"
 #include "internal.h"
 #include "wgrad_wino.h"
+#include "wgrad_wh.h"
 
 namespace sinddm {
 
@@ -501,8 +502,11 @@ static void wgrad_launch_t(const WgradArgs& a, unsigned grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_mfma_kernel<MT, TAPS>), dim3(grid), dim3(WG_THREADS), lds, st, a);
 }
 
+// amax_d / amax_i: the per-sample running maxima of dout / in when their producers maintain them (training on the binary16
+// kernels): the Winograd-domain weight gradient then runs on the binary16 matrix pipe too (wgrad_wh.h)
 static int wgrad_launch(const float* zero, const float* dout, const float* in, float* gw, float* gb, int B, int H, int W,
-                        int Cin, int Cout, int taps, hipStream_t st, float* scr = nullptr) {
+                        int Cin, int Cout, int taps, hipStream_t st, float* scr = nullptr, const float* amax_d = nullptr,
+                        const float* amax_i = nullptr) {
     WgradArgs a{};
     a.zero = zero;
     a.dout = dout; a.in = in; a.gw = gw; a.gb = gb;
@@ -534,13 +538,18 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
         if (e != hipSuccess) return (int)e;
         // rows of 16-byte groups (W % 4 == 0): the variant with 16-byte DMA and ds_read_b64 operands
         const bool wide = SINDDM_WGRAD_WIDE && W % 4 == 0;
+        const bool h16 = SINDDM_WGRAD_WH && wide && amax_d && amax_i && wh_enabled();
+        w.amax_d = amax_d; w.amax_i = amax_i;
         const size_t lds = (size_t)WW_STAGES * (wide ? WX_BUF : WW_BUF) * sizeof(float);
         // (more than 64 KB of dynamic LDS needs the per-function opt-in: once per kernel and process, its result checked)
         static const hipError_t attr_wide = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_wide_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WW_STAGES * WX_BUF * sizeof(float)));
         static const hipError_t attr_dword = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WW_STAGES * WW_BUF * sizeof(float)));
+        static const hipError_t attr_h16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wh_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WW_STAGES * WX_BUF * sizeof(float)));
         if ((wide ? attr_wide : attr_dword) != hipSuccess) return (int)(wide ? attr_wide : attr_dword);
+        if (h16 && attr_h16 != hipSuccess) return (int)attr_h16;
         ConvProfiler& prof = conv_profiler();
         const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
         if (rec) {
@@ -551,13 +560,16 @@ static int wgrad_launch(const float* zero, const float* dout, const float* in, f
             }
             (void)hipEventRecord(prof.ev[2 * prof.used], st);
         }
-        if (wide) hipLaunchKernelGGL(wgrad_wino_wide_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
+        if (h16) hipLaunchKernelGGL(wgrad_wh_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
+        else if (wide) hipLaunchKernelGGL(wgrad_wino_wide_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
         else hipLaunchKernelGGL(wgrad_wino_kernel, dim3((unsigned)nwg), dim3(WW_THREADS), lds, st, w);
         SINDDM_LAUNCH_CHECK();
         if (rec) {
             (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
             const double fl = 2.0 * B * H * W * (double)Cout * Cin * 9.0;
-            prof.note(4, fl, fl * 16.0 / 36.0);      // kind 4 = Winograd-domain weight gradient, F(2x2): 16/36 executed
+            // kind 4 = Winograd-domain weight gradient, F(2x2): 16/36 executed; generation 8 = binary16 pieces, four terms
+            if (h16) prof.note(4, fl, fl * 16.0 / 36.0 * 4.0, 8);
+            else prof.note(4, fl, fl * 16.0 / 36.0);
         }
         hipLaunchKernelGGL(wgrad_unstage_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scr, gw, Cin, n);
         SINDDM_LAUNCH_CHECK();
@@ -1108,7 +1120,10 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
         if (rc) return rc;
     }
     // conv2 + residual projection weight grads
-    rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr);
+    // (the running maxima of g = conv2's forward input and of h = conv1's are the forward half of tb.amax, slots 2l + 1 / 2l)
+    const bool wha = wh1 && wh_plan_ok(b.cin, b.cout) && wh_applies(B, H, W, b.cin, b.cout);
+    rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr,
+                      wh2 ? amax_b + 2 * l : nullptr, wh2 ? tb.amax + 2 * l + 1 : nullptr);
     if (rc) return rc;
     if (b.res_w >= 0) {
         rc = wgrad_launch(zp, dO, xin, grads + b.res_w, grads + b.res_b, B, H, W, b.cin, b.cout, 1, st);
@@ -1129,7 +1144,8 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
                             b.cout, k.mt2[l], k.cb2[l], B, H, W, st);
     if (rc) return rc;
     // conv1 weight grads, dH = dgrad_conv1(dU)
-    rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr);
+    rc = wgrad_launch(zp, dU, tb.h[l], grads + b.c1_w, grads + b.c1_b, B, H, W, b.cin, b.cout, 9, st, tb.wscr,
+                      wha ? amax_b + 2 * l + 1 : nullptr, wha ? tb.amax + 2 * l : nullptr);
     if (rc) return rc;
     if (wh1) {
         ConvArgs c{};

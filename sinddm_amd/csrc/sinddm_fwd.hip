@@ -1153,6 +1153,7 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
 }
 
 bool wh_applies(int B, int H, int W, int cin, int cout) { return conv_wh_applies(B, H, W, cin, cout); }
+bool wh_enabled() { return SINDDM_CONV_WH && conv_wh_flag() != 0; }
 int wh_conv(const ConvArgs& c, hipStream_t st) { return conv_wh_launch(c, st); }
 int wh_pack(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st) {
     return wh_pack_launch(w, wsinv, img, cin, cout, transpose, st);

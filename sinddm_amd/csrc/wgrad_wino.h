@@ -65,6 +65,8 @@ struct WwArgs {
     int B, H, W, Cin, Cout;
     int coblks, ciblks;
     int tilesX, tilesY, ntiles;
+    const float* amax_d;   // wgrad_wh.h only: per-sample running max |dout| / |in| ([B][AMAX_STRIDE] floats each)
+    const float* amax_i;
     WwMap map;
 };
 
