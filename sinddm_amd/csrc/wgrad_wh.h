@@ -54,7 +54,11 @@ __device__ __forceinline__ void wgh_split(f32x4 v, float sc, wgh4& hi, wgh4& lo)
     const f32x4 s = v * sc;
     hi = __builtin_convertvector(s, wgh4);
     if (WGH_ABL & 16) { lo = hi; return; }
-    const f32x4 r = s - __builtin_convertvector(hi, f32x4);
+    // remainder as one fused multiply-add per value with the binary16 piece as an operand (v_fma_mix_f32): v * sc is exact
+    // (power of two), so fma(v, sc, -hi) = s - hi exactly
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(v[i], sc, -(float)hi[i]);
     lo = __builtin_convertvector(r, wgh4);
 }
 
