@@ -72,10 +72,12 @@ def test_conv_wino4_owns_the_agprs():
 WGRAD_TU = """
 #include "conv_mfma.h"
 #include "wgrad_wino.h"
+#include "wgrad_wh.h"
 namespace sinddm {
 ConvProfiler& conv_profiler() { static ConvProfiler p; return p; }
 void touch(const WwArgs& w, hipStream_t st) {
     hipLaunchKernelGGL(wgrad_wino_wide_kernel, dim3(1), dim3(WW_THREADS), 0, st, w);
+    hipLaunchKernelGGL(wgrad_wh_kernel, dim3(1), dim3(WW_THREADS), 0, st, w);
 }
 }
 """
@@ -124,6 +126,32 @@ def test_wgrad_wide_kernel_reads_lds_with_plain_b64_and_dmas_16_bytes():
     assert re.search(r"Occupancy:\s+4\b", meta)
     scratch = int(re.search(r"ScratchSize:\s+(\d+)", meta).group(1))
     assert scratch <= 64, scratch                  # (a few spilled address registers in the 4-term copies; none holds data)
+
+    # the binary16 sibling (wgrad_wh.h): one k-step per tile -- 30 / 20 / 10 MFMAs of the binary16 shape in each of the 48 loop
+    # bodies, operands read as ds_read_b128, the split's remainder as ONE v_fma_mix_f32 per value (16 per fragment pair: 8 / 7 / 6
+    # fragments per tile), tiles by 16-byte LDS-DMA, four waves per SIMD
+    m = re.search(r"^(_ZN6sinddm15wgrad_wh_kernel\w+):", s, re.M)
+    assert m
+    end = s.index(".Lfunc_end", m.start())
+    body = [l.strip() for l in s[m.start():end].split("\n") if l.strip() and not l.strip().startswith(";")]
+    assert sum(l.startswith("v_mfma_f32_16x16x32_f16") for l in body) == 16 * (30 + 20 + 10)
+    assert not [l for l in body if l.startswith("v_mfma") and "16x16x32_f16" not in l]
+    assert sum(l.startswith("v_fma_mix_f32") for l in body) == 16 * 4 * (8 + 7 + 6)
+    assert not [l for l in body if l.startswith("v_cvt_f32_f16")], "the remainder went back to conversion + subtract"
+    assert sum(l.startswith("ds_read_b128") for l in body) > 600 and not [l for l in body if l.startswith("ds_read2")]
+    assert any(l.startswith("buffer_load_dwordx4") and " lds" in l for l in body)
+    counts, cur = [], 0
+    for l in body:
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            counts.append(cur)
+            cur = 0
+        elif l.startswith("v_mfma"):
+            cur += 1
+    counts.append(cur)
+    assert sorted(c for c in counts if c) == sorted([30] * 16 + [20] * 16 + [10] * 16)
+    meta = s[end:end + 8000]
+    assert re.search(r"Occupancy:\s+4\b", meta)
+    assert int(re.search(r"ScratchSize:\s+(\d+)", meta).group(1)) <= 64
 
 
 TU_WH = """
