@@ -30,6 +30,9 @@ namespace sinddm {
 #ifndef SINDDM_WGRAD_WINO     // 1: Winograd-domain 3x3 weight gradient
 #define SINDDM_WGRAD_WINO 1
 #endif
+#ifndef SINDDM_DWG_ROWS       // 1: depthwise weight gradient of wide aligned images on the register-window kernel
+#define SINDDM_DWG_ROWS 1
+#endif
 #ifndef SINDDM_WGRAD_WH       // 1: ... and on the binary16 matrix pipe (wgrad_wh.h) when the operands' running maxima exist (training on conv_wh)
 #define SINDDM_WGRAD_WH 1
 #endif

@@ -3,6 +3,7 @@
 // dedicated MFMA kernel with pixels as the GEMM K dimension), L1 loss, fused Adam / EMA.
 // Replaces autograd through SinDDMNet + torch.optim.Adam + EMA of the reference
 // (SinDDM/models.py:578-611, trainer.py:134,194-214, models.py:18-31).
+#include <utility>
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino4.h"
@@ -733,6 +734,92 @@ __global__ __launch_bounds__(256) void dwconv5_wgrad_kernel(const float* __restr
     }
 }
 
+// Register-window variant for rows that are a multiple of 4 pixels and at least 192 wide (round 5; the LDS-tile kernel above
+// ran at 0.55 of the HBM rate: scalar loads, two barriers per tile).  Same block per (channel, sample) plane, same reduction;
+// wave w walks DOWN its quarter of the rows, lane = 4 consecutive columns: per row one 16-byte load of dh and three aligned
+// 16-byte loads of x (columns -4 .. +7 around the lane's four; the neighbours' overlap is served by L1), a window of six x rows
+// in registers (the newest is in flight while the five above it are used), 100 FMAs per row into the lane's 25 tap sums.
+// No LDS, no barrier until the reduction.
+template <class F, int... I>
+__device__ __forceinline__ void dwg_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+__global__ __launch_bounds__(256) void dwconv5_wgrad_rows_kernel(const float* __restrict__ dh, const float* __restrict__ x,
+                                                                 float* __restrict__ gw, float* __restrict__ gb,
+                                                                 float* __restrict__ dcond, int cond_stride, int C, int H,
+                                                                 int W) {
+    __shared__ float red[4][26];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const size_t plane = ((size_t)b * C + c) * H * W;
+    const float* xs = x + plane;
+    const float* ds = dh + plane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[26];
+#pragma unroll
+    for (int k = 0; k < 26; ++k) acc[k] = 0.f;
+    const int rows_per = (H + 3) / 4;
+    const int r0 = wave * rows_per, r1 = min(H, r0 + rows_per);
+    const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+    for (int xb = 0; xb < W; xb += 256) {
+        const int gx = xb + 4 * lane;
+        const bool act = gx < W;
+        const bool okl = act && gx >= 4, okr = act && gx + 4 < W;
+        f32x4 xw[6][3];
+        auto load_row = [&](int y, f32x4 (&r)[3]) {
+            const bool oky = y >= 0 && y < H;
+            const float* q = xs + (size_t)y * W + gx;
+            r[0] = (oky && okl) ? *reinterpret_cast<const f32x4*>(q - 4) : zero4;
+            r[1] = (oky && act) ? *reinterpret_cast<const f32x4*>(q) : zero4;
+            r[2] = (oky && okr) ? *reinterpret_cast<const f32x4*>(q + 4) : zero4;
+        };
+        // rows r0 - 2 .. r0 + 2 -> slots 0 .. 4; row y + 3 is requested while row y is processed
+#pragma unroll
+        for (int k = 0; k < 5; ++k) load_row(r0 - 2 + k, xw[k]);
+        for (int y0 = r0; y0 < r1; y0 += 6) {
+            dwg_static_for_impl([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const int y = y0 + u;
+                if (y < r1) {                                   // (wave-uniform)
+                    load_row(y + 3, xw[(u + 5) % 6]);
+                    const f32x4 d = act ? *reinterpret_cast<const f32x4*>(ds + (size_t)y * W + gx) : zero4;
+                    acc[25] += (d.x + d.y) + (d.z + d.w);
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky) {
+                        const f32x4(&r)[3] = xw[(u + ky) % 6];  // x row y + ky - 2
+                        const float w12[12] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w, r[2].x, r[2].y, r[2].z, r[2].w};
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) {
+                            // tap (ky, kx): x[y + ky - 2][gx + j + kx - 2] = window column j + kx + 2
+                            float a = acc[ky * 5 + kx];
+                            a = fmaf(d.x, w12[kx + 2], a);
+                            a = fmaf(d.y, w12[kx + 3], a);
+                            a = fmaf(d.z, w12[kx + 4], a);
+                            a = fmaf(d.w, w12[kx + 5], a);
+                            acc[ky * 5 + kx] = a;
+                        }
+                    }
+                }
+            }, std::make_integer_sequence<int, 6>{});
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 26; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 26) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (threadIdx.x < 25) atomicAdd(&gw[c * 25 + threadIdx.x], v);
+        else {
+            atomicAdd(&gb[c], v);
+            dcond[(size_t)b * cond_stride + c] = v;
+        }
+    }
+}
+
 // =====================================================================================
 // conditioning-path backward (tiny; ONE workgroup, phases separated by __syncthreads)
 // =====================================================================================
@@ -1161,8 +1248,12 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
                             b.cin, k.mt1[l], k.cb1[l], B, H, W, st);
     if (rc) return rc;
     // depthwise weight/bias grads and the per-sample condition grads
-    hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
-                       grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
+    if (SINDDM_DWG_ROWS && W % 4 == 0 && W >= 192)
+        hipLaunchKernelGGL(dwconv5_wgrad_rows_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
+                           grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
+    else
+        hipLaunchKernelGGL(dwconv5_wgrad_kernel, dim3(b.cin, B), dim3(256), 0, st, dH, xin, grads + b.dw_w,
+                           grads + b.dw_b, tb.dcond + b.cond_off, P.cond_stride, b.cin, H, W);
     SINDDM_LAUNCH_CHECK();
     // data grad w.r.t. the block input: dw^T(dH) + residual path
     if (dst) {
