@@ -368,6 +368,53 @@ def test_net_backward_binary16_convs_vs_float64():
           max(errs.items(), key=lambda kv: kv[1][0]), "fp32-path class worst", worst_f)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 6, 192), (2, 13, 320), (1, 3, 516), (2, 9, 188)])
+def test_depthwise_weight_gradient_kernels_vs_float64(B, H, W):
+    """The depthwise 5x5 weight / bias / condition gradients of ONE block (sinddm_debug_block_train, block 1: 80 -> 160) on
+    wide aligned images -- the register-window kernel (W % 4 == 0, W >= 192: one and several 256-column bands, fewer rows
+    than waves) -- and on a width the LDS-tile kernel keeps (188), against a float64 torch evaluation of the block
+    (reference SinDDM/models.py:69-80 under autograd)."""
+    import torch.nn.functional as F
+    from sinddm_amd import _lib
+    from sinddm_amd.models import SinDDMNet, _workspace
+    lib = _lib.load()
+    dim, li, cin, cout = 160, 1, 80, 160
+    net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+    sd = closed_form_state_dict(dim)
+    net.load_state_dict(sd)
+    x = hash_randn((B, cin, H, W), 71)
+    cb = 0.1 * hash_randn((B, cin), 72)
+    gy = hash_randn((B, cout, H, W), 73) / (B * 3 * H * W)
+    D = torch.float64
+    xr = x.to(D).requires_grad_(True)
+    cbr = cb.to(D).requires_grad_(True)
+    w = {k: sd[f"l2.{k}"].to(D).requires_grad_(True) for k in ("ds_conv.weight", "ds_conv.bias", "net.0.weight", "net.0.bias",
+                                                                "net.2.weight", "net.2.bias", "res_conv.weight", "res_conv.bias")}
+    h = F.conv2d(xr, w["ds_conv.weight"], w["ds_conv.bias"], padding=2, groups=cin) + cbr[:, :, None, None]
+    o = F.conv2d(F.gelu(F.conv2d(h, w["net.0.weight"], w["net.0.bias"], padding=1)), w["net.2.weight"], w["net.2.bias"], padding=1)
+    o = o + F.conv2d(xr, w["res_conv.weight"], w["res_conv.bias"])
+    o.backward(gy.to(D))
+    ws = _workspace(DEV, lib.sinddm_train_workspace_bytes(dim, B, H, W), tag="train")
+    y = torch.empty(B, cout, H, W, device=DEV)
+    gx = torch.empty(B, cin, H, W, device=DEV)
+    dc = torch.zeros(B, cin, device=DEV)
+    gr = torch.zeros_like(net.flat_params)
+    xd, cbd, gyd = x.to(DEV), cb.to(DEV), gy.to(DEV)
+    _lib.check(lib.sinddm_debug_block_train(_lib.ptr(net.flat_params), _lib.ptr(net.packed_weights()), _lib.ptr(net.packed_weights_bwd()),
+                                            dim, li, _lib.ptr(xd), _lib.ptr(cbd), _lib.ptr(gyd), _lib.ptr(y), _lib.ptr(gx), _lib.ptr(gr),
+                                            _lib.ptr(dc), B, H, W, ws.data_ptr(), ws.numel(), _lib.stream_ptr(DEV)), "sinddm_debug_block_train")
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu().double(), o.detach()) < 5e-6
+    assert rel_l2(gx.cpu().double(), xr.grad) < 2e-5
+    assert rel_l2(dc.cpu().double(), cbr.grad) < 5e-5
+    gr = gr.cpu()
+    for name, p in net.named_parameters():
+        if name in ("l2.ds_conv.weight", "l2.ds_conv.bias"):
+            off = (p.data_ptr() - net.flat_params.data_ptr()) // 4
+            got = gr[off:off + p.numel()].reshape(p.shape).double()
+            assert rel_l2(got, w[name[3:]].grad) < 5e-5, (name, rel_l2(got, w[name[3:]].grad))
+
+
 def test_weight_gradients_reproducible_run_to_run():
     """Regression test of the LDS-DMA publication race: the same backward three times -- the only
     legitimate run-to-run difference is the order of the fp32 atomics (<= 1e-6 rel-L2); the race showed as 1e-4 .. 2e-3 in
