@@ -45,7 +45,8 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W);
 
 /* ... and for TRAINING launches (sinddm_net_forward_train / sinddm_net_backward: plain rows, no padding): 8 = the forward
  * 3x3 convs and both data-gradient convs of the dim -> dim blocks take conv_wh (same rule as inference; needs W % 4 == 0),
- * else the value of sinddm_debug_conv_path.  The weight gradients stay on the fp32 pipe either way. */
+ * else the value of sinddm_debug_conv_path.  With 8 the 3x3 weight gradients of those convs run on the binary16 pipe too
+ * (wgrad_wh.h); the 1x1 / depthwise / first-conv weight gradients stay fp32. */
 int sinddm_debug_train_path(int dim, int B, int H, int W);
 
 /* Process-global switch of the binary16 hi/lo 3x3 kernels: bit 0 = conv_h2.h (direct implicit GEMM; 7 from

@@ -23,7 +23,8 @@
 // thread = (tile, channel) gathers 24 values, inverse transform A^T M A, scale, bias, GELU / GELU' / residual, 16-byte stores.
 //
 // Replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] / nn.Conv2d(dim_out, dim_out, 3, padding=1) [+ residual] of
-// SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80) for inference launches with enough items per CU.
+// SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80) -- inference, training forward and (with transposed, tap-flipped weight
+// images) both data gradients -- for launches with enough items per CU.
 #pragma once
 #include <utility>
 #include "conv_h2.h"
