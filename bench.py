@@ -16,17 +16,20 @@ training step (SURVEY 8(d) secondary metric) and `strong_scaling_n1` (the 1/8 sh
 single-GPU shard efficiency).  --config / --batch (weak) and --global-batch (strong headline) override.  The line
 carries comm_world_size (== n_gpus, asserted), per-rank min / max step time and the time of the all-gather alone.
 
-`roofline` describes the dominant kernel of the headline step, the 3x3 convolutions.  Launches with >= 2 work items of
-8x64 pixels per CU run conv_h2_kernel: a direct implicit GEMM on v_mfma_f32_32x32x16_f16 with every fp32 operand
-split into two binary16 pieces (three MFMA terms per product, fp32 accumulate: fp32-equivalent, tests/test_gpu_h2.py);
-`achieved` = the binary16 MFMA FLOPs a launch executes (3 x 2*9*Cin*Cout per pixel, padded items and channels
-included) / the average launch time measured with HIP events around every launch on the launch stream in a second,
-untimed pass; `peak` = 2500 TF/s (dense binary16 MFMA), and `fp32_equivalent` prices the same launches as fp32 work
-against BOTH the fp32 matrix peak (157.3 TF/s) and the split scheme's ceiling (2500 / 3).  `fp32_mfma_path` = the same
-steps with the kernel switched off (sinddm_debug_set_h2(0): Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32), measured in
-the same process.  Smaller launches stay on the fp32-MFMA Winograd kernels (conv_wino4 / 3 / 2).  `traffic` = HBM bytes
-per launch from the PMC passes of the profile named in `traffic_source` (another box), or null.  `cpu_baseline` = the
-oracle's CPU restatement of the same step.
+`roofline` describes the dominant kernel of the headline step, the 3x3 convolutions.  Launches with >= 12 work items of
+8x32 pixels x 80 channels per CU on images of >= 12 000 pixels run conv_wh_kernel: Winograd F(2x4,3x3) whose 24
+frequency GEMMs run on v_mfma_f32_16x16x32_f16 with the transformed input and the transformed weights each split into two
+binary16 pieces (all four MFMA terms, fp32 accumulate: fp32-equivalent, tests/test_gpu_h2.py).  `achieved` / `frac` follow
+SURVEY.md 8(d): ALGORITHMIC FLOPs of a launch (2*9*Cin*Cout per pixel and sample) / the average launch time measured with
+HIP events around every launch on the launch stream in a second, untimed pass, against `peak` = 2500 TF/s (dense
+binary16 MFMA).  `mfma_busy` prices the FLOPs the matrix pipe EXECUTES (4 terms x 24 frequencies per 8 outputs = 12 MACs
+per pixel, ci, co on whole items) against the same peak -- the pipe's duty cycle, not the roofline fraction.
+`fp32_equivalent` prices the same launches against the fp32 matrix peak (157.3 TF/s).  `fp32_mfma_path` = the same steps
+with the binary16 kernels switched off (Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32), measured on the same box.  Smaller
+launches stay on the fp32-MFMA Winograd kernels (conv_wino4 / 3 / 2).  `traffic` = HBM bytes per launch from the PMC
+passes of the profile named in `traffic_source` (another box); `traffic_stale` is true when that profile was taken with a
+library built from other sources than the ones benchmarked here.  `cpu_baseline` = the oracle's CPU restatement of the
+same step.
 
 `--gpus N` without a torch.distributed environment re-launches itself under torch.distributed.run with N ranks
 (one per GPU, RCCL) and fails if the node has fewer than N devices.
@@ -261,9 +264,12 @@ def _traffic(cfg_name):
     try:
         t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
         c = t.get(cfg_name, {})
-        return c.get("conv_bytes_per_launch"), c.get("source")
+        from sinddm_amd import build as _b
+        # the PMC passes describe the library they ran: flag a record taken with other kernel sources than today's
+        stale = c.get("lib_source_sha256") != _b.stamp() if c else None
+        return c.get("conv_bytes_per_launch"), c.get("source"), stale
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
@@ -298,10 +304,12 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     t0p = time.perf_counter()
     two = d.two_streams
     d.two_streams = False          # (one stream in the instrumented pass: the per-launch event times of two overlapping half-batches would add up to more than the step -- ADVICE r4)
-    with _PowerSampler() as power:
-        img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
-        ctx.barrier()
-    d.two_streams = two
+    try:
+        with _PowerSampler() as power:
+            img = d._run_steps(img, s, t_seq[warmup:warmup + steps])
+            ctx.barrier()
+    finally:
+        d.two_streams = two
     dt_prof = time.perf_counter() - t0p
     dom_ms, dom_n, dom_fl, dom_ex = _prof(lib, 1, 0)          # the Winograd 3x3 launches only
     mix = {}
@@ -318,7 +326,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
     avg_launch_ms = dom_ms / max(1, dom_n)
     algorithmic = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     executed = dom_ex / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic, traffic_src = _traffic(cfg_name)
+    traffic, traffic_src, traffic_stale = _traffic(cfg_name)
     F16_KERNELS = ("conv_wh_kernel", "conv_h2_kernel")
     h2_only = len(mix) > 0 and all(k in F16_KERNELS for k in mix)
     fp32_only = not any(k in F16_KERNELS for k in mix)
@@ -328,7 +336,7 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
         "measured_in": "second, untimed pass over the same steps with HIP events around each launch "
                        f"({round(dt_prof / steps * 1e3, 4)} ms/step with the events on)",
         "power": power.summary(),
-        "traffic": traffic, "traffic_source": traffic_src,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
         "hbm_frac": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                      if traffic and avg_launch_ms > 0 else None),
         "executed_flops_per_launch": round(dom_ex / max(1, dom_n)),
@@ -349,12 +357,18 @@ def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
                        "conv_h2_kernel: direct implicit-GEMM 3x3 conv on v_mfma_f32_32x32x16_f16, fp32 operands split into two "
                        "binary16 pieces, three MFMA terms per product, fp32 accumulate (7 launches per step)")
                       + "; this run's launches by kernel: " + ", ".join(f"{k} x{v['launches']}" for k, v in mix.items()),
-            "achieved": round(executed, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
-            "flops_counted": ("binary16 MFMA FLOPs as executed: 4 terms x 24 frequencies per 8 outputs (= 12 MACs per pixel, ci, co instead "
-                              "of the direct form's 9) on whole 8x32-pixel items" if wh else
-                              "binary16 MFMA FLOPs as executed: 3 terms x 2*9*Cin*Cout per pixel on whole 8x64-pixel items and "
-                              "32-channel column tiles (C_out = 80 runs as 96)"),
+            # algorithmic FLOPs (2*9*Cin*Cout per pixel and sample) / measured launch time against the peak of the pipe
+            # the products run on
+            "achieved": round(algorithmic, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(algorithmic / F16_MFMA_PEAK_TFLOPS, 4),
+            "flops_counted": "algorithmic: 2*9*Cin*Cout FLOP per pixel and sample of every launch (direct-convolution count, no padding)",
+            # the pipe's duty cycle: FLOPs the matrix cores execute (not a roofline fraction: Winograd executes 12 MACs per
+            # (pixel, ci, co) in four binary16 terms where the direct form counts 9)
+            "mfma_busy": {"executed_tflops": round(executed, 2), "frac_of_peak": round(executed / F16_MFMA_PEAK_TFLOPS, 4),
+                          "flops_counted": ("binary16 MFMA FLOPs as executed: 4 terms x 24 frequencies per 8 outputs (= 12 MACs per pixel, ci, co) "
+                                            "on whole 8x32-pixel items" if wh else
+                                            "binary16 MFMA FLOPs as executed: 3 terms x 2*9*Cin*Cout per pixel on whole 8x64-pixel items and "
+                                            "32-channel column tiles (C_out = 80 runs as 96)")},
             "note": "the kernel is bound by the socket's power limit and by operand delivery (U fragments out of L2, input transform), "
                     "not by the matrix pipe: see roofline.power, fp32_equivalent and DESIGN.md section 5",
             # the same launches priced as fp32 work (direct-convolution FLOPs / time) against both peaks the judge asked for

@@ -1112,6 +1112,13 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         rc = conv_launch(c1, b.mt, st);
     }
     if (rc) return rc;
+    // conv2 on a binary16 kernel reads the running max of g (slot amax + 1): conv_wh / conv_h2 / the C_in = 3 kernel publish it
+    // from their epilogues, the fp32 kernels do not (dim = 80 / 240: block 1 has C_in = dim / 2, not a multiple of 16, so conv1
+    // stays on an fp32 kernel while conv2 qualifies) -- one pass over g then
+    if (h2b && !(wha || h2a || (b.cin == 3 && c3 && !(v3 && b.pk_w1f >= 0) && !(wino && b.pk_wc1 >= 0 && b.cin % 4 == 0)))) {
+        rc = amax_tensor_launch(gbuf, amax + 1, B, (long long)b.cout * H * W, st);
+        if (rc) return rc;
+    }
     ConvArgs c2{};
     c2.in = gbuf; c2.out = obuf;
     c2.B = B; c2.H = H; c2.W = W; c2.Cin = b.cout; c2.Cout = b.cout;

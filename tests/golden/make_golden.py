@@ -446,6 +446,48 @@ def g14():
          plan_len=np.array(len(plan)), ideal=np.array(ideal))
 
 
+def g_chain(cfg_name, out_name, scale_mul=(1, 1)):
+    """Full chain of a headline config from the REFERENCE: T=1000, B=1, dim=160, hash noise -- G14's recipe for any
+    config of g11_img_scales.json.  G18 = C3 (6 scales, finest 411x512: 2 551 chained evaluations, the workload bench.py
+    is quoted on); G19 = C5 with scale_mul=(2, 4) (the odd 364x1092 geometry, reference sample_via_scale size selection
+    models.py:549-568 with custom_sample=False).  Stores the per-scale outputs as float16 deltas?  No: float32, compressed."""
+    with open(os.path.join(HERE, "g11_img_scales.json")) as f:
+        c = json.load(f)[cfg_name]
+    net = ref_net(160)
+    sizes = [tuple(s) for s in c["sizes"]]
+    d = make_diffusion(net, sizes, c["rescale_losses"], c["scale_factor"], c["n_scales"], c["T"],
+                       scale_mul=tuple(scale_mul))
+    ideal = d.num_timesteps_ideal
+    assert ideal == c["num_timesteps_ideal"]
+    plan = [("init", 0, 0)] + [("step", 0, t) for t in reversed(range(c["T"]))]
+    for s in range(1, c["n_scales"]):
+        plan += [("renoise", s, 0)] + [("step", s, t) for t in reversed(range(ideal[s]))]
+    feeder = NoiseFeeder(plan)
+    outs = []
+    import time
+    t0 = time.time()
+    with patched_noise(feeder), torch.no_grad():
+        if tuple(scale_mul) == (1, 1):
+            img = d.sample(batch_size=1, s=0)
+        else:
+            # trainer.py:247-252: scale 0 of a scale_mul run is sampled at the multiplied size
+            img = d.sample(batch_size=1, scale_0_size=(int(d.image_sizes[0][0] * scale_mul[0]),
+                                                       int(d.image_sizes[0][1] * scale_mul[1])), s=0)
+        outs.append(img)
+        print(out_name, "scale 0 done", tuple(img.shape), time.time() - t0, flush=True)
+        for s in range(1, c["n_scales"]):
+            if tuple(scale_mul) == (1, 1):
+                img = d.sample_via_scale(1, outs[-1], s=s, scale_mul=(1, 1), custom_sample=True,
+                                         custom_img_size_idx=s, custom_t=ideal[1:][s - 1])
+            else:
+                img = d.sample_via_scale(1, outs[-1], s=s, scale_mul=tuple(scale_mul), custom_t=ideal[1:][s - 1])
+            outs.append(img)
+            print(out_name, "scale", s, "done", tuple(img.shape), time.time() - t0, flush=True)
+    assert feeder.i == len(plan), (feeder.i, len(plan))
+    save(out_name, **{f"out_s{i}": o for i, o in enumerate(outs)},
+         plan_len=np.array(len(plan)), ideal=np.array(ideal), scale_mul=np.array(scale_mul))
+
+
 def g10(meta, workdir):
     """20 reference train() steps at dim=32, B=2, with injected (s, t, noise)."""
     c1 = meta["C1"]
@@ -742,6 +784,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         g14()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g18":
+        g_chain("C3", "g18_chain_c3.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "g19":
+        g_chain("C5", "g19_chain_c5_mul24.npz", scale_mul=(2, 4))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g12":
         workdir = tempfile.mkdtemp(prefix="sinddm_golden_")
         try:
@@ -766,6 +814,8 @@ def main():
         g16(workdir)
         g14()
         g17(meta)
+        g_chain("C3", "g18_chain_c3.npz")
+        g_chain("C5", "g19_chain_c5_mul24.npz", scale_mul=(2, 4))
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

@@ -59,6 +59,68 @@ def test_full_chain_c2_t1000_batch16_golden(golden):
     assert max(worst) < 1e-4, worst
 
 
+def _chain_vs_fixture(cfg, g, B, expect_paths, scale_mul=(1, 1)):
+    """Full chain of config `cfg` at batch B, every chain fed the fixture's B = 1 hash noise; cumulative and restarted at
+    every scale from the reference's own previous-scale image.  Returns (worst cumulative, worst restarted) rel-L2 per scale."""
+    from sinddm_amd import _lib
+    net, d = build_diffusion(cfg, dim=160, device=DEV)
+    sizes = CONFIGS[cfg]["sizes"]
+    n = len(sizes)
+    assert d.num_timesteps_ideal == list(g["ideal"])
+    assert int(g["plan_len"]) == 1 + sum(d.num_timesteps_ideal) + (n - 1)
+    lib = _lib.load()
+    shapes = [tuple(g[f"out_s{i}"].shape[2:]) for i in range(n)]
+    took = [lib.sinddm_debug_infer_path(160, B, h, w) for (h, w) in shapes]
+    assert took[-len(expect_paths):] == expect_paths, took
+
+    def noise(kind, shape, s, t, dev):
+        one = hash_randn((1,) + tuple(shape[1:]), noise_key(kind, s, t)).to(dev)
+        return one.expand(shape).contiguous()
+
+    d.noise_fn = noise
+    sm = tuple(scale_mul)
+
+    def first():
+        if sm == (1, 1):
+            return d.sample(batch_size=B, s=0)
+        return d.sample(batch_size=B, scale_0_size=(int(d.image_sizes[0][0] * sm[0]), int(d.image_sizes[0][1] * sm[1])), s=0)
+
+    def nxt(prev, s):
+        if sm == (1, 1):
+            return d.sample_via_scale(B, prev, s=s, scale_mul=(1, 1), custom_sample=True, custom_img_size_idx=s,
+                                      custom_t=d.num_timesteps_ideal[1:][s - 1])
+        return d.sample_via_scale(B, prev, s=s, scale_mul=sm, custom_t=d.num_timesteps_ideal[1:][s - 1])
+
+    outs = [first()]
+    for s in range(1, n):
+        outs.append(nxt(outs[-1], s))
+    cum = []
+    for i, o in enumerate(outs):
+        assert tuple(o.shape[2:]) == shapes[i], (i, o.shape, shapes[i])     # int() truncation of the scaled sizes (models.py:558-563)
+        o = o.cpu()
+        cum.append(max(rel_l2(o[b:b + 1], g[f"out_s{i}"]) for b in (0, B // 2, B - 1)))
+    del outs
+    iso = []
+    for s in range(1, n):
+        prev = torch.from_numpy(g[f"out_s{s - 1}"]).to(DEV).expand(B, -1, -1, -1).contiguous()
+        o = nxt(prev, s).cpu()
+        iso.append(max(rel_l2(o[b:b + 1], g[f"out_s{s}"]) for b in (0, B // 2, B - 1)))
+    return cum, iso
+
+
+def test_full_chain_c3_t1000_batch64_golden(golden):
+    """G18: the chain of the workload bench.py's headline is quoted on -- C3, 6 scales, T = 1000, 2 551 chained evaluations,
+    finest 411x512 -- against the REFERENCE's images (reference SinDDM/trainer.py:226-285, models.py:501-568), at the
+    benchmarked batch of 64: the four finest scales (116x145 ... 411x512: 1 008 chained evaluations) run on conv_wh, the
+    kernel that is 81 % of the headline step.  north_star: 1e-4 rel-L2 per scale, cumulative and restarted per scale."""
+    g = golden("g18_chain_c3.npz")
+    cum, iso = _chain_vs_fixture("C3", g, 64, [8, 8, 8, 8])
+    print("C3 chain at B=64, rel-L2 per scale (cumulative):", ["%.2e" % e for e in cum])
+    print("C3 chain at B=64, rel-L2 per scale (restarted from the reference's previous scale):", ["%.2e" % e for e in iso])
+    assert max(cum) < 1e-4, cum
+    assert max(iso) < 1e-4, iso
+
+
 def _c1_trainer(tmp_path, golden, dim=160):
     from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
     from sinddm_amd.trainer import MultiscaleTrainer

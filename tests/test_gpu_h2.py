@@ -132,3 +132,130 @@ def test_fused_chain_h2_vs_winograd(h2_switch):
     err = rel_l2(outs[0], outs[1])
     print(f"[h2 mode {lib.mode}] 12 fused steps, h2 vs fp32-MFMA Winograd: {err:.3e}")
     assert err < 2e-5
+
+
+# ---- round 6: the gate on non-benign weights and batches (VERDICT r5 "what's weak" 1c) --------------------------------
+def _gate(net, sd, x, t, scale, idx, label, factor=1.5):
+    got = net.infer(x.to(DEV), t.to(DEV), 0, float(scale)).cpu()
+    assert torch.isfinite(got).all(), label
+    worst = 0.0
+    for i in idx:
+        ref64 = _net_forward_f64(sd, x[i:i + 1], t[i:i + 1], scale)
+        ref32 = O.net_forward(sd, x[i:i + 1], t[i:i + 1], scale)
+        e_k, e_32 = rel_l2(got[i:i + 1], ref64), rel_l2(ref32, ref64)
+        print(f"[{label}] sample {i}: vs float64  conv_wh {e_k:.3e}  fp32 oracle {e_32:.3e}  ratio {e_k / e_32:.2f}")
+        assert e_k <= factor * e_32, (label, i, e_k, e_32)
+        worst = max(worst, e_k / e_32)
+    return worst
+
+
+def _heavy_tailed_state_dict(log2_span, seed=5):
+    """Closed-form weights with per-channel gains 2^U(-span, +span) on the hidden tensors of blocks l2 and l3 -- g (conv1's
+    output / conv2's input) and the block output -- compensated on the consumer side so the network stays finite: the per-
+    sample activation scale (one running max for all channels of a tensor) and the per-output-channel weight scale of the
+    binary16 kernels then see channels 2^(2 span) apart."""
+    sd = {k: v.clone() for k, v in closed_form_state_dict(160).items()}
+    gen = torch.Generator().manual_seed(seed)
+
+    def gains(n):
+        return torch.exp2((torch.rand(n, generator=gen) * 2 - 1) * log2_span)
+
+    for blk in ("l2", "l3"):
+        a = gains(sd[f"{blk}.net.0.weight"].shape[0])                 # conv1 output channels: g = GELU(a u)
+        sd[f"{blk}.net.0.weight"] *= a.view(-1, 1, 1, 1)
+        sd[f"{blk}.net.0.bias"] *= a
+        sd[f"{blk}.net.2.weight"] /= a.view(1, -1, 1, 1)              # conv2 input channels
+    # block l2's output channels (conv2 + residual projection) x b, undone by l3's depthwise conv and its residual identity:
+    # l3 reads x through ds_conv (per channel: / b) -- its identity residual keeps the gain, so l3's conv2 output is scaled too
+    b = gains(160)
+    for k in ("l2.net.2.weight", "l2.res_conv.weight"):
+        sd[k] *= b.view(-1, 1, 1, 1)
+    for k in ("l2.net.2.bias", "l2.res_conv.bias"):
+        sd[k] *= b
+    sd["l3.ds_conv.weight"] /= b.view(-1, 1, 1, 1)
+    sd["l3.net.2.weight"] *= b.view(-1, 1, 1, 1)                      # l3 out = conv2 + x: both carry b
+    sd["l3.net.2.bias"] *= b
+    sd["l4.ds_conv.weight"] /= b.view(-1, 1, 1, 1)
+    sd["l4.res_conv.weight"] /= b.view(1, -1, 1, 1)
+    return sd
+
+
+@pytest.mark.parametrize("span", [4, 8])
+def test_gate_heavy_tailed_channel_gains(span):
+    """Per-channel gains 2^U(-span, span) on conv inputs AND outputs of the dim -> dim blocks."""
+    lib = _lib()
+    B, H, W = 16, 186, 248
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 8
+    sd = _heavy_tailed_state_dict(span)
+    net = _net(160, sd)
+    x = hash_randn((B, 3, H, W), 777) * 0.9
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    _gate(net, sd, x, t, 2, [0, B - 1], f"channel gains 2^+-{span}")
+
+
+def test_gate_one_sample_2e12_louder_than_the_batch():
+    """One chain of the batch at 2^12 times the others' amplitude: the activation scales are per SAMPLE, so neither the
+    loud chain nor its neighbours may lose bits."""
+    lib = _lib()
+    B, H, W = 16, 186, 248
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 8
+    sd = closed_form_state_dict(160)
+    net = _net(160, sd)
+    x = hash_randn((B, 3, H, W), 778) * 0.9
+    x[5] *= 4096.0
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    _gate(net, sd, x, t, 1, [4, 5, 6], "sample 5 x 2^12")
+
+
+def test_gate_after_training_steps_dim160():
+    """Weights that an optimiser has touched: 12 Adam steps (lr 1e-3: every weight moves by ~1e-2, the size of a 160 -> 160
+    weight itself) of the library's own training step at dim = 160 on the GPU, then frozen and held to the same gate."""
+    from sinddm_amd.configs import build_diffusion
+    lib = _lib()
+    net, d = build_diffusion("C2", dim=160, device=torch.device(DEV))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    s = 4
+    H, W = d.image_sizes[s]
+    Bt = 8
+    x0 = (hash_randn((Bt, 3, H, W), 4001) * 0.5).clamp(-1, 1).to(DEV)
+    xr = (hash_randn((Bt, 3, H, W), 4002) * 0.5).clamp(-1, 1).to(DEV)
+    torch.manual_seed(3)
+    for _ in range(12):
+        opt.zero_grad()
+        loss = d((x0, xr), s)
+        loss.backward()
+        opt.step()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    moved = float((sd["l3.net.0.weight"] - closed_form_state_dict(160)["l3.net.0.weight"]).abs().mean())
+    assert moved > 2e-3, moved
+    B = 16
+    assert lib.sinddm_debug_infer_path(160, B, H, W) == 8
+    x = hash_randn((B, 3, H, W), 779) * 0.9
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    _gate(net, sd, x, t, float(s), [0, B - 1], "after 12 Adam steps")
+
+
+@pytest.mark.parametrize("dim", [80, 240])
+def test_conv2_on_binary16_behind_an_fp32_conv1(dim):
+    """dim = 80 / 240: block l2 has C_in = dim / 2 (40 / 120: not a multiple of 16), so its conv1 stays on an fp32 kernel
+    that does not publish the running max of g while conv2 (dim -> dim) qualifies for conv_wh: the library
+    then measures g in one pass.  Inputs scaled so that |g| * 20 would overflow binary16 with a scale of 1."""
+    lib = _lib()
+    B, H, W = 48, 186, 248
+    assert lib.sinddm_debug_infer_path(dim, B, H, W) == 8
+    sd = {k: v.clone() for k, v in closed_form_state_dict(dim).items()}
+    for k in ("l1.net.2.weight", "l1.net.2.bias", "l1.res_conv.weight", "l1.res_conv.bias"):
+        sd[k] = sd[k] * 4096.0                                       # every later tensor ~ 4 000
+    for k in ("l2.ds_conv.bias", "l2.time_reshape.weight", "l2.time_reshape.bias"):
+        sd[k] = sd[k] * 4096.0
+    net = _net(dim, sd)
+    x = hash_randn((B, 3, H, W), 780) * 0.9
+    t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
+    got = net.infer(x.to(DEV), t.to(DEV), 0, 1.0).cpu()
+    assert torch.isfinite(got).all()
+    idx = [0, B - 1]
+    ref64 = _net_forward_f64(sd, x[idx], t[idx], 1)
+    ref32 = O.net_forward(sd, x[idx], t[idx], 1)
+    e_k, e_32 = rel_l2(got[idx], ref64), rel_l2(ref32, ref64)
+    print(f"[dim {dim}] vs float64  library {e_k:.3e}  fp32 oracle {e_32:.3e}")
+    assert e_k <= 1.5 * e_32, (e_k, e_32)

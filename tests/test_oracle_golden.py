@@ -195,6 +195,33 @@ def test_g14_chain_c2_head(golden):
         assert rel_l2(x, g["out_s1"]) < 1e-5
 
 
+def test_g18_chain_c3_scale1_restart(golden):
+    """G18 (the reference's full C3 chain -- the workload bench.py is quoted on: 6 scales, T=1000, 2 551 evaluations,
+    finest 411x512): the oracle re-runs scale 1 (76x95, 543 steps: bilinear upsample of the reference's scale-0 image,
+    q_sample at total_t = 543 without the -1, models.py:504-518, then the reverse steps) and must land on the reference's
+    scale-1 image; the index bookkeeping of every scale is checked exactly.  Bounded so the CPU suite stays short -- all
+    six scales are the GPU test's job (tests/test_gpu_chain_pin.py)."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g18_chain_c3.npz")
+    c3 = meta["C3"]
+    sched = _sched(meta, "C3")
+    assert sched["num_timesteps_ideal"] == list(g["ideal"]) == [1000, 543, 408, 289, 192, 119]
+    assert int(g["plan_len"]) == 1 + sum(sched["num_timesteps_ideal"]) + 5
+    sizes = [tuple(s) for s in c3["image_sizes_hw"]]
+    for i, hw in enumerate(sizes):
+        assert g[f"out_s{i}"].shape == (1, 3) + hw
+    sd = closed_form_state_dict(160)
+    s = 1
+    with torch.no_grad():
+        up = O.bilinear_upsample(torch.from_numpy(g["out_s0"]), sizes[s])
+        total_t = sched["num_timesteps_ideal"][s]
+        x = O.q_sample(sched, up, torch.full((1,), total_t, dtype=torch.long),
+                       hash_randn((1, 3) + sizes[s], noise_key("renoise", s, 0)))
+        for t in range(total_t - 1, -1, -1):
+            x = O.p_sample(sched, sd, x, t, s, hash_randn((1, 3) + sizes[s], noise_key("step", s, t)), up)
+    assert rel_l2(x, g["out_s1"]) < 1e-5
+
+
 def test_adam_and_lr_restatement():
     torch.manual_seed(0)
     p = torch.randn(50)
