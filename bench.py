@@ -73,8 +73,8 @@ def parse():
     ap.add_argument("--no-train", action="store_true", help="skip the training-step leg")
     ap.add_argument("--no-ab", action="store_true", help="skip the fp32-MFMA A/B leg (fp32_mfma_path)")
     ap.add_argument("--seed", type=int, default=1234)
-    ap.add_argument("--h2", type=int, default=None, choices=(0, 1, 3),
-                    help="A/B only: binary16 hi/lo 3x3 kernels (sinddm_debug_set_h2): 0 off, 1 direct kernel only, 3 (default) Winograd + direct")
+    ap.add_argument("--fp32-convs", action="store_true",
+                    help="A/B only: every net launches with SINDDM_DIM_FP32_CONVS (3x3 convs on the fp32 matrix pipe instead of conv_wh)")
     return ap.parse_args()
 
 
@@ -272,13 +272,15 @@ def _traffic(cfg_name):
         return None, None, None
 
 
-def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None):
+def steps_leg(ctx, lib, cfg_name, B, steps, warmup, seed, global_batch=None, fp32_convs=None):
     """Finest-scale reverse steps of one config: the timed region + the roofline of the dominant kernel.  B = chains of
     THIS rank; global_batch = chains of the whole job (strong scaling: ranks may differ by one)."""
     from sinddm_amd.configs import CONFIGS, build_diffusion
     cfg = CONFIGS[cfg_name]
     torch.manual_seed(seed + ctx.rank)
     net, d = build_diffusion(cfg_name, dim=160, device=ctx.dev)
+    if fp32_convs is not None:
+        net.fp32_convs = fp32_convs
     n_scales = len(cfg["sizes"])
     s = n_scales - 1
     mul = cfg.get("scale_mul", (1, 1))
@@ -481,6 +483,66 @@ def full_sample_leg(ctx, d, cfg, B, sizes=None):
             "finite": bool(torch.isfinite(cur).all())}
 
 
+def train_loop_leg(ctx, opt_steps=24, warmup=6, seed=1234):
+    """SURVEY 8(d) secondary metric as the reference runs it: MultiscaleTrainer.train() itself (reference trainer.py:189-214) --
+    a scale per optimizer step drawn from multinomial(num_timesteps_trained) (train_full_t: uniform over the 5 scales),
+    gradient_accumulate_every = 2 forward/backward passes at batch 32, fused Adam, MultiStepLR, EMA copy every 10 steps --
+    on a synthetic C2 pyramid (random images of the C2 sizes written as the scale_i/ PNG folders the trainer stages)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from PIL import Image
+    from sinddm_amd.configs import CONFIGS, build_diffusion
+    from sinddm_amd.trainer import MultiscaleTrainer
+    from sinddm_amd import _lib
+    lib = _lib.load()
+    cfg = CONFIGS["C2"]
+    n = len(cfg["sizes"])
+    tmp = tempfile.mkdtemp(prefix="sinddm_bench_train_")
+    try:
+        rng = np.random.RandomState(seed)
+        for i, (w, h) in enumerate(cfg["sizes"]):
+            for sub in (f"scale_{i}", f"scale_{i}_recon"):
+                os.makedirs(os.path.join(tmp, sub), exist_ok=True)
+                Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(tmp, sub, "synthetic.png"))
+        torch.manual_seed(seed + ctx.rank)
+        net, d = build_diffusion("C2", 160, ctx.dev)
+        tr = MultiscaleTrainer(d, folder=tmp + "/", n_scales=n, scale_factor=cfg["scale_factor"], image_sizes=cfg["sizes"],
+                               train_batch_size=32, train_lr=2e-5, train_num_steps=warmup, gradient_accumulate_every=2,
+                               step_start_ema=2000, update_ema_every=10, save_and_sample_every=10 ** 9, avg_window=100,
+                               results_folder=os.path.join(tmp, "results"), device=ctx.dev)
+        picks = []
+        pick = tr._pick_scale
+
+        def logged(w):
+            s = pick(w)
+            picks.append(int(s))
+            return s
+
+        tr._pick_scale = logged
+        tr.train()                                     # warm-up: allocations, every scale's workspace
+        del picks[:]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.train_num_steps = warmup + opt_steps
+        tr.train()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        hist = [picks.count(i) for i in range(n)]
+        paths = [int(lib.sinddm_debug_train_path(160, 32, h, w)) for (w, h) in cfg["sizes"]]
+        px = sum(c * 2 * 32 * h * w for c, (w, h) in zip(hist, cfg["sizes"]))
+        return {"workload": f"MultiscaleTrainer.train(): C2 pyramid ({n} scales, uniform scale pick), batch 32, gradient_accumulate_every 2, "
+                            "fused Adam + MultiStepLR + EMA copy every 10 steps, dim=160, synthetic images",
+                "optimizer_steps": opt_steps, "optimizer_steps_per_sec": round(opt_steps / dt, 3),
+                "ms_per_optimizer_step": round(dt / opt_steps * 1e3, 2),
+                "scale_picks": hist, "train_path_per_scale": paths,
+                "pixel_passes_per_sec": round(px / dt, 1),
+                "net_tflops_3x_forward": round(3 * NET_FLOP_PER_PIXEL * px / dt / 1e12, 1),
+                "finite": bool(torch.isfinite(net.flat_params).all())}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def train_leg(ctx, steps=5, warmup=2):
     """SURVEY 8(d) secondary metric: train() steps/s at batch 32 on the C2 finest scale (forward + backward + fused
     Adam; reference trainer.py:194-213 with gradient_accumulate_every=1)."""
@@ -637,8 +699,9 @@ def main():
     from sinddm_amd import _lib
     from sinddm_amd.configs import CONFIGS
     lib = _lib.load()
-    if args.h2 is not None:
-        lib.sinddm_debug_set_h2(args.h2)
+    if args.fp32_convs:
+        from sinddm_amd.models import SinDDMNet
+        SinDDMNet.fp32_convs = True          # class attribute: every net of this process (a per-call option of the C ABI, no library state)
 
     from sinddm_amd.dist import shard_sizes
 
@@ -675,17 +738,15 @@ def main():
     torch.cuda.empty_cache()
     # the same steps on the fp32-MFMA Winograd path (the binary16 hi/lo kernel switched off), same process, same box
     fp32_path = None
-    if args.h2 is None and not args.no_ab and any(k in head["roofline"]["kernel_mix"] for k in ("conv_wh_kernel", "conv_h2_kernel")):
-        fp32_path = {}
-        for mode, key, note in ((0, "fp32_winograd", "sinddm_debug_set_h2(0): Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32, the round-4 path"),
-                                (1, "binary16_direct", "sinddm_debug_set_h2(1): conv_h2_kernel, direct implicit GEMM, 3 binary16 terms")):
-            lib.sinddm_debug_set_h2(mode)
-            ra, st_a = steps_leg(ctx, lib, cfg_name, B, min(args.steps, 10), min(args.warmup, 2), args.seed, G)
-            del st_a
-            torch.cuda.empty_cache()
-            fp32_path[key] = {"ms_per_step": ra["ms_per_step"], "value": ra["value"], "kernel_mix": ra["roofline"]["kernel_mix"],
-                              "frac": ra["roofline"]["frac"], "peak": ra["roofline"]["peak"], "power": ra["roofline"]["power"], "note": note}
-        lib.sinddm_debug_set_h2(3)
+    if not args.fp32_convs and not args.no_ab and "conv_wh_kernel" in head["roofline"]["kernel_mix"]:
+        ra, st_a = steps_leg(ctx, lib, cfg_name, B, min(args.steps, 10), min(args.warmup, 2), args.seed, G, fp32_convs=True)
+        del st_a
+        torch.cuda.empty_cache()
+        fp32_path = {"fp32_winograd": {
+            "ms_per_step": ra["ms_per_step"], "value": ra["value"], "kernel_mix": ra["roofline"]["kernel_mix"],
+            "frac": ra["roofline"]["frac"], "peak": ra["roofline"]["peak"], "power": ra["roofline"]["power"],
+            "note": "the same steps launched with SINDDM_DIM_FP32_CONVS: Winograd F(2x4,3x3) on v_mfma_f32_16x16x4_f32, the round-4 path; "
+                    "frac = EXECUTED fp32 MFMA FLOPs / 157.3 TF/s"}}
 
     nested = {}
     if not args.no_strong and not strong:
@@ -732,6 +793,7 @@ def main():
     train = None
     if ctx.rank == 0 and ctx.world == 1 and not args.no_train:
         train = train_leg(ctx)
+        train["train_loop"] = train_loop_leg(ctx)
 
     if ctx.rank == 0:
         line = {

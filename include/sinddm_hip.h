@@ -27,7 +27,13 @@
 extern "C" {
 #endif
 
-#define SINDDM_ABI_VERSION 2
+#define SINDDM_ABI_VERSION 3    /* 3 (round 6): option bits in `dim`; packed-weight layout without the conv_h2 images; sinddm_debug_set_h2 removed */
+
+/* Every `dim` argument below = SinDDMNet's width (reference SinDDM/models.py:86, main.py --dim) in its low 16 bits, plus
+ * per-call option bits above them.  Options change which kernels a call launches, never a buffer layout or size. */
+#define SINDDM_DIM_FP32_CONVS 0x10000  /* keep every 3x3 convolution on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32 Winograd
+                                        * kernels) instead of the binary16 hi/lo kernel (conv_wh.h): for A/B measurements and
+                                        * parity tests of the two paths; results agree to fp32 rounding (tests/test_gpu_h2.py) */
 
 #define SINDDM_E_BADARG   (-1)  /* null pointer / non-positive size            */
 #define SINDDM_E_BADSHAPE (-2)  /* dim/channels not supported by the kernels   */

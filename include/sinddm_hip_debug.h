@@ -1,6 +1,6 @@
 /*
  * sinddm_hip_debug.h -- measurement hooks of libsinddm_hip.so.  NOT part of the drop-in boundary (sinddm_hip.h):
- * these are the only entry points that keep process-global mutable state (a table of hipEvents), they are off
+ * these are the only entry points that keep process-global mutable state (a table of hipEvents -- nothing a result depends on), they are off
  * unless sinddm_prof_begin() was called, they are not thread-safe, and a production caller never needs them.
  * bench.py uses them for the `roofline` object (HIP events around every MFMA conv launch, on the launch stream).
  * The reference has no counterpart (it has no profiling).
@@ -39,8 +39,7 @@ int sinddm_debug_conv_path(int dim, int B, int H, int W);
 
 /* The same question for INFERENCE launches (sinddm_net_forward / sinddm_sample_chain: rows padded to 4 floats inside the
  * workspace): 8 = conv_wh (Winograd F(2x4), binary16 hi/lo frequency GEMMs: >= 12 items of 8x32 pixels x 80 channels per CU, images of >= 12 000 pixels),
- * 7 = conv_h2 (binary16 hi/lo direct kernel: only with switch value 1, >= 2 items of 8x64 pixels per CU),
- * else the value sinddm_debug_conv_path gives for the padded shape. */
+ * else the value sinddm_debug_conv_path gives for the padded shape.  `dim` may carry SINDDM_DIM_FP32_CONVS (never 8 then). */
 int sinddm_debug_infer_path(int dim, int B, int H, int W);
 
 /* ... and for TRAINING launches (sinddm_net_forward_train / sinddm_net_backward: plain rows, no padding): 8 = the forward
@@ -48,12 +47,6 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W);
  * else the value of sinddm_debug_conv_path.  With 8 the 3x3 weight gradients of those convs run on the binary16 pipe too
  * (wgrad_wh.h); the 1x1 / depthwise / first-conv weight gradients stay fp32. */
 int sinddm_debug_train_path(int dim, int B, int H, int W);
-
-/* Process-global switch of the binary16 hi/lo 3x3 kernels: bit 0 = conv_h2.h (direct implicit GEMM; 7 from
- * sinddm_debug_infer_path), bit 1 = conv_wh.h (Winograd F(2x4) with binary16 frequency GEMMs; 8, preferred where both
- * apply).  0 keeps the launches that qualify on the fp32-MFMA Winograd kernels; the default is 3.  Returns the previous value.
- * For A/B measurements and parity tests of the paths in one process; the library itself never changes it. */
-int sinddm_debug_set_h2(int on);
 
 /* ONE SinDDMConvBlock (l = 0..3 of the plan of SinDDMNet(dim); reference SinDDM/models.py:51-80) forward + backward on
  * its own: x (B, C_in, H, W), cond_bias (B, C_in) = the block's per-sample condition (time_reshape(mlp(cond)),

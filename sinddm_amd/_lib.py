@@ -19,11 +19,14 @@ ABI_SYMBOLS = (
     "sinddm_abi_version", "sinddm_param_count", "sinddm_param_tensors", "sinddm_param_offset",
     "sinddm_packed_count", "sinddm_workspace_bytes", "sinddm_pack_weights", "sinddm_net_forward",
     "sinddm_q_sample", "sinddm_reverse_step", "sinddm_reverse_step_edit", "sinddm_upsample_bilinear", "sinddm_prof_begin", "sinddm_prof_end", "sinddm_prof_end2", "sinddm_prof_end3", "sinddm_debug_wgrad_map", "sinddm_debug_conv_path",
-    "sinddm_debug_block_train", "sinddm_debug_set_h2", "sinddm_debug_infer_path", "sinddm_debug_train_path",
+    "sinddm_debug_block_train", "sinddm_debug_infer_path", "sinddm_debug_train_path",
     "sinddm_train_workspace_bytes", "sinddm_packed_bwd_count", "sinddm_pack_weights_bwd",
     "sinddm_net_forward_train", "sinddm_net_backward", "sinddm_l1_loss_fwd_bwd", "sinddm_adam_ema_step",
     "sinddm_cond_embed", "sinddm_cond_stride", "sinddm_sample_chain", "sinddm_sample_chain2", "sinddm_normal_fill",
 )
+
+
+DIM_FP32_CONVS = 0x10000     # SINDDM_DIM_FP32_CONVS of include/sinddm_hip.h: option bit of every `dim` argument
 
 
 class StepCoefs(C.Structure):
@@ -87,7 +90,6 @@ def load() -> C.CDLL:
                                  C.POINTER(C.c_double), i]),
         "sinddm_debug_wgrad_map": (i, [i, i, i64, i, C.POINTER(C.c_uint32), i, C.POINTER(C.c_int32), i]),
         "sinddm_debug_conv_path": (i, [i, i, i, i]),
-        "sinddm_debug_set_h2": (i, [i]),
         "sinddm_debug_infer_path": (i, [i, i, i, i]),
         "sinddm_debug_train_path": (i, [i, i, i, i]),
         "sinddm_debug_block_train": (i, [p, p, p, i, i, p, p, p, p, p, p, p, i, i, i, p, sz, p]),

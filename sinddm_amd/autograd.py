@@ -27,7 +27,7 @@ class _NetTrainFn(torch.autograd.Function):
         nbytes = lib.sinddm_train_workspace_bytes(net.dim, B, H, W)
         ws = _workspace(x.device, nbytes, tag="train")
         _lib.check(lib.sinddm_net_forward_train(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(t),
-                                                0, float(scale), _lib.ptr(out), net.dim, B, H, W, ws.data_ptr(),
+                                                0, float(scale), _lib.ptr(out), net.dim_arg, B, H, W, ws.data_ptr(),
                                                 ws.numel(), _lib.stream_ptr(x.device)), "sinddm_net_forward_train")
         key = ws.data_ptr()
         _WS_GEN[key] = _WS_GEN.get(key, 0) + 1
@@ -54,7 +54,7 @@ class _NetTrainFn(torch.autograd.Function):
         net.bind_grads()
         _lib.check(lib.sinddm_net_backward(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(packed_bwd),
                                            _lib.ptr(x), _lib.ptr(grad_out), _lib.ptr(net.flat_grads),
-                                           _lib.ptr(gx) if gx is not None else None, net.dim, B, H, W,
+                                           _lib.ptr(gx) if gx is not None else None, net.dim_arg, B, H, W,
                                            ctx.ws.data_ptr(), ctx.ws.numel(), _lib.stream_ptr(x.device)),
                    "sinddm_net_backward")
         return gx, None, None, None, None

@@ -62,7 +62,7 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
-// conv_h2.h: running max |x| of the tensors the binary16 kernel reads, PER SAMPLE ([B][AMAX_STRIDE] floats, slot 2 l + i =
+// split16.h / conv_wh.h: running max |x| of the tensors the binary16 kernel reads, PER SAMPLE ([B][AMAX_STRIDE] floats, slot 2 l + i =
 // input of conv i of block l): a sample's scale -- and so its result, bit for bit -- does not depend on what else is in the batch
 constexpr int AMAX_STRIDE = 8;
 

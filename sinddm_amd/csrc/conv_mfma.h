@@ -41,8 +41,8 @@ struct ConvArgs {
     int coblks;
     int mtp;             // (Winograd kernel) m-tiles per PACKED output-channel block; 0 = same as the kernel's MT
     int act;             // 0 none, 1 GELU, 2 multiply by GELU'(aux)
-    const float* wsinv;  // (conv_h2.h) per output channel 2^-e of the packed binary16 weight image
-    const float* amax_in;   // (conv_h2.h) per-sample device scalars [b * AMAX_STRIDE]: max |in[b]| (its producer maintains them); nullptr = unit scale
+    const float* wsinv;  // (conv_wh.h) per output channel 2^-e of the packed binary16 weight image
+    const float* amax_in;   // (conv_wh.h) per-sample device scalars [b * AMAX_STRIDE]: max |in[b]| (its producer maintains them); nullptr = unit scale
     float* amax_out;     // optional per-sample device scalars [b * AMAX_STRIDE]: running max |out[b]| (guarded atomicMax), for the conv that reads `out` next
     int Wt;              // 0, or the TRUE image width when rows are padded to W (a multiple of 4) inside the library's own
                          // workspace: columns Wt .. W-1 of every input row hold zeros and are written as zeros

@@ -55,8 +55,8 @@ int conv3x3_path(int cout, int cin, int coblks, int B, int H, int W);
 // conv_wh.h (the Winograd F(2x4) kernel with binary16 hi/lo frequency GEMMs) lives in sinddm_fwd.hip; the backward TU
 // reaches it through these: the dispatch rule, one launch, the weight image of a conv (transpose = 1: of its data gradient)
 struct ConvArgs;
-bool wh_applies(int B, int H, int W, int cin, int cout);
-bool wh_enabled();       // compiled in and switched on (sinddm_debug_set_h2 bit 1)
+bool wh_applies(const NetPlan& P, int B, int H, int W, int cin, int cout);   // (false for every launch of a plan with fp32_convs)
+bool wh_enabled();       // compiled in
 int wh_conv(const ConvArgs& c, hipStream_t st);
 int wh_pack(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st);
 // max |x| of every sample of x[B][per_sample] (per_sample % 4 == 0) into amax[b * AMAX_STRIDE] (zeroed by the caller)

@@ -10,14 +10,6 @@ constexpr int KC = 8;          // input channels per LDS chunk (two k-steps of t
 constexpr int TIME_DIM = 32;   // models.py:101
 constexpr int CHANNELS = 3;
 
-// conv_h2.h (binary16 hi/lo direct conv): packed image [chunk of 16 ci][ty][tx][piece][n-tile of 32 co][lane][8 x f16]
-inline int h2_nt_for(int cout) { return (cout + 31) / 32; }
-inline long long h2_image_halfs(int cin, int nt) { return (long long)(cin / 16) * 9 * 2 * nt * 64 * 8; }
-inline bool h2_shape_ok(int cin, int cout) {
-    const int nt = h2_nt_for(cout);
-    return cin >= 16 && cin % 16 == 0 && (nt == 3 || nt == 5);
-}
-
 // conv_wh.h (Winograd F(2x4) with binary16 hi/lo frequency GEMMs): packed image [co block of 80][chunk of 16 ci][f 24][n 5][piece][k half][co 16][8 x f16]
 inline bool wh_plan_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout % 80 == 0; }
 inline long long wh_plan_halfs(int cin, int cout) { return (long long)(cout / 80) * (cin / 16) * 24 * 5 * 512; }
@@ -40,8 +32,6 @@ struct BlockPlan {
     int64_t pk_wc1, pk_wc2;    // pk_wc1 = -1 when conv1 stays on the direct kernel (C_in < 8)
     // Winograd F(2x4,3x3) images of conv_wino3.h ([coblk][chunk][i][ks][q 0..7][lane][4]); -1 = shape not supported
     int64_t pk_w1f, pk_w2f;
-    // conv_h2.h images (float offsets; 16-byte aligned) and their per-output-channel 2^-e arrays; -1 = shape not supported
-    int64_t pk_h1, pk_h2, pk_hs1, pk_hs2;
     // conv_wh.h images and their per-output-channel 2^-e arrays; -1 = shape not supported
     int64_t pk_q1, pk_q2, pk_qs1, pk_qs2;
     int cond_off;  // offset of this block's per-sample bias inside the cond vector
@@ -56,14 +46,20 @@ struct NetPlan {
     int ntensors;
     int64_t tensor_off[64];
     int cond_stride;   // floats per sample of the cond-bias vector (sum of cin, padded to 4)
+    bool fp32_convs;   // per-call option SINDDM_DIM_FP32_CONVS: no launch takes the binary16 hi/lo kernels
     bool ok;
 };
 
 inline int mt_for(int cout) { return (cout % 80 == 0) ? 5 : ((cout % 32 == 0) ? 2 : 1); }
 inline int co_lds_for(int mt) { int m = mt * 16; return (m % 32 == 16) ? m : m + 16; }
 
-inline NetPlan make_plan(int dim) {
+// dim_arg: the `dim` argument of the C ABI = SinDDMNet's width in the low 16 bits + option bits above (sinddm_hip.h);
+// the layouts (parameters, packed images, workspaces) do not depend on the options
+inline NetPlan make_plan(int dim_arg) {
     NetPlan p{};
+    const int dim = dim_arg & 0xFFFF;
+    p.fp32_convs = (dim_arg & 0x10000) != 0;
+    if (dim_arg < 0 || (dim_arg >> 17) != 0) { p.ok = false; return p; }
     p.ok = dim >= 2 && dim % 2 == 0 && dim <= 1024;
     p.dim = dim;
     p.half = dim / 2;
@@ -118,14 +114,6 @@ inline NetPlan make_plan(int dim) {
         if (f24 && b.cin >= 16 && b.cin % 16 == 0) { b.pk_w1f = q; q += (int64_t)b.coblks * b.nchw1 * 32768; } else b.pk_w1f = -1;
         if (f24 && b.cout % 16 == 0) { b.pk_w2f = q; q += (int64_t)b.coblks * b.nchw2 * 32768; } else b.pk_w2f = -1;
         q = (q + 63) / 64 * 64;
-        if (h2_shape_ok(b.cin, b.cout)) {
-            b.pk_h1 = q; q += h2_image_halfs(b.cin, h2_nt_for(b.cout)) / 2;
-            b.pk_hs1 = q; q += h2_nt_for(b.cout) * 32;
-        } else b.pk_h1 = b.pk_hs1 = -1;
-        if (h2_shape_ok(b.cout, b.cout)) {
-            b.pk_h2 = q; q += h2_image_halfs(b.cout, h2_nt_for(b.cout)) / 2;
-            b.pk_hs2 = q; q += h2_nt_for(b.cout) * 32;
-        } else b.pk_h2 = b.pk_hs2 = -1;
         if (wh_plan_ok(b.cin, b.cout)) {
             b.pk_q1 = q; q += wh_plan_halfs(b.cin, b.cout) / 2;
             b.pk_qs1 = q; q += (b.cout + 63) / 64 * 64;

@@ -1200,15 +1200,15 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
     // the two 3x3 data-gradient convs on the binary16 hi/lo Winograd kernel (conv_wh.h) where its rule takes the launch;
     // `amax_b` = the backward half of tb.amax (zeroed by the caller): slot 2l = max |dO| per sample (maintained by the kernel
     // that wrote dO when `dO_published`), slot 2l + 1 = max |dU| (by the first conv's epilogue)
-    const bool wh2 = amax_b && wino_enabled() && k.qdg2[l] >= 0 && wh_applies(B, H, W, b.cout, b.cout);
-    const bool wh1 = wh2 && k.qdg1[l] >= 0 && wh_applies(B, H, W, b.cout, b.cin);
+    const bool wh2 = amax_b && wino_enabled() && k.qdg2[l] >= 0 && wh_applies(P, B, H, W, b.cout, b.cout);
+    const bool wh1 = wh2 && k.qdg1[l] >= 0 && wh_applies(P, B, H, W, b.cout, b.cin);
     if (wh2 && !dO_published) {
         rc = amax_tensor_launch(dO, amax_b + 2 * l, B, (long long)b.cout * H * W, st);
         if (rc) return rc;
     }
     // conv2 + residual projection weight grads
     // (the running maxima of g = conv2's forward input and of h = conv1's are the forward half of tb.amax, slots 2l + 1 / 2l)
-    const bool wha = wh1 && wh_plan_ok(b.cin, b.cout) && wh_applies(B, H, W, b.cin, b.cout);
+    const bool wha = wh1 && wh_plan_ok(b.cin, b.cout) && wh_applies(P, B, H, W, b.cin, b.cout);
     rc = wgrad_launch(zp, dO, tb.g[l], grads + b.c2_w, grads + b.c2_b, B, H, W, b.cout, b.cout, 9, st, tb.wscr,
                       wh2 ? amax_b + 2 * l : nullptr, wh2 ? tb.amax + 2 * l + 1 : nullptr);
     if (rc) return rc;
@@ -1266,7 +1266,7 @@ static int block_backward(const NetPlan& P, const BwdPack& k, int l, const float
         }
         // (dst is the next block's dO: its running max comes out of this launch when that block's convs will want it)
         float* pub = nullptr;
-        if (amax_b && l > 0 && wino_enabled() && k.qdg2[l - 1] >= 0 && wh_applies(B, H, W, b.cin, b.cin)) pub = amax_b + 2 * (l - 1);
+        if (amax_b && l > 0 && wino_enabled() && k.qdg2[l - 1] >= 0 && wh_applies(P, B, H, W, b.cin, b.cin)) pub = amax_b + 2 * (l - 1);
         rc = dwconv_launch(dH, params + b.dw_w, nullptr, nullptr, 0, radd, 1, dst, B, b.cin, H, W, st, 0, 0, pub);
         if (rc) return rc;
     }
@@ -1406,7 +1406,7 @@ int sinddm_debug_train_path(int dim, int B, int H, int W) {
     NetPlan p = make_plan(dim);
     if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
     const BlockPlan& b = p.blk[2];
-    if (wino_enabled() && b.pk_q2 >= 0 && wh_applies(B, H, W, b.cout, b.cout)) return 8;
+    if (wino_enabled() && b.pk_q2 >= 0 && wh_applies(p, B, H, W, b.cout, b.cout)) return 8;
     return conv3x3_path(b.cout, b.cout, b.coblks, B, H, W);
 }
 

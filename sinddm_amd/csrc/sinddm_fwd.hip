@@ -3,7 +3,6 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino4.h"
-#include "conv_h2.h"
 #include "conv_wh.h"
 #include "internal.h"
 namespace sinddm {
@@ -216,17 +215,9 @@ static int pack_forward(const NetPlan& P, const float* params, float* packed, hi
         rc = pack_launch(params, packed, f, st);
         if (rc) return rc;
     }
-    // the binary16 hi/lo images of conv_h2.h and their per-channel scales
+    // the binary16 hi/lo images of conv_wh.h and their per-channel scales
     for (int l = 0; l < 4; ++l) {
         const BlockPlan& b = P.blk[l];
-        if (b.pk_h1 >= 0) {
-            rc = h2_pack_launch(params + b.c1_w, packed + b.pk_hs1, packed + b.pk_h1, b.cin, b.cout, 0, st);
-            if (rc) return rc;
-        }
-        if (b.pk_h2 >= 0) {
-            rc = h2_pack_launch(params + b.c2_w, packed + b.pk_hs2, packed + b.pk_h2, b.cout, b.cout, 0, st);
-            if (rc) return rc;
-        }
         if (b.pk_q1 >= 0) {
             rc = wh_pack_launch(params + b.c1_w, packed + b.pk_qs1, packed + b.pk_q1, b.cin, b.cout, 0, st);
             if (rc) return rc;
@@ -991,7 +982,7 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // conditioning rows: one per sample (sinddm_net_forward) or one per sampler step of a run (sinddm_sample_chain: every
 // sample of the batch shares the step's t, so a whole run of steps is embedded by ONE cond_kernel launch)
 constexpr int CHAIN_COND_ROWS = 1024;
-// ... followed by the running-max scalars of one network evaluation (conv_h2.h: [sample][AMAX_STRIDE], slot 2 l + i = max
+// ... followed by the running-max scalars of one network evaluation (split16.h: [sample][AMAX_STRIDE], slot 2 l + i = max
 // |input| of conv i of block l, maintained by that tensor's producer kernel, zeroed at the start of the evaluation)
 static size_t amax_region_bytes(int B) { return ((size_t)B * AMAX_STRIDE * sizeof(float) + 255) / 256 * 256; }
 static size_t cond_region_bytes(const NetPlan& P, int B) {
@@ -1003,7 +994,7 @@ static size_t cond_region_bytes(const NetPlan& P, int B) {
 #endif
 // row pitch of the library's own activation buffers in inference: W rounded up to 4 floats
 // Padded rows need every producer to write the pad columns as zeros (ConvArgs::Wt): the depthwise kernels, the C_in = 3
-// conv, the Winograd kernels of conv_wino2/3/4.h and conv_h2 do; the direct implicit-GEMM kernel (conv_mfma.h) and the
+// conv, the Winograd kernels of conv_wino2/3/4.h and conv_wh do; the direct implicit-GEMM kernel (conv_mfma.h) and the
 // first-generation Winograd kernel do not.  So the pitch is a property of the PLAN: rows are padded only when
 // block_forward routes every 3x3 conv of the network to a Wt-aware kernel (all channel counts multiples of 4, C_in = 3 or
 // >= 8) -- other widths (--dim 10, 20, 28 ...) keep plain rows and the kernels' edge variants.
@@ -1059,17 +1050,14 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
                   int cond_stride, float* hbuf, float* gbuf, float* obuf, float* upre, int B, int H, int W, hipStream_t st,
                   int Wt, float* amax) {
     const BlockPlan& b = P.blk[l];
-    // binary16 hi/lo direct kernel (conv_h2.h): inference launches with a few 8x64 items per CU; `amax` = this block's two
-    // running-max scalars (input of conv1, input of conv2), maintained by the kernels that produce those tensors
-    // ... or, first choice, the Winograd F(2x4) kernel with binary16 hi/lo frequency GEMMs (conv_wh.h)
-    const bool wha = amax && b.pk_q1 >= 0 && conv_wh_applies(B, H, W, b.cin, b.cout);
-    const bool whb = amax && b.pk_q2 >= 0 && conv_wh_applies(B, H, W, b.cout, b.cout);
-    const bool h2a = wha || (amax && b.pk_h1 >= 0 && conv_h2_applies(B, H, W, b.cin, b.cout));
-    const bool h2b = whb || (amax && b.pk_h2 >= 0 && conv_h2_applies(B, H, W, b.cout, b.cout));
+    // the Winograd F(2x4) kernel with binary16 hi/lo frequency GEMMs (conv_wh.h) where its rule takes the launch; `amax` = this
+    // block's two running-max scalars (input of conv1, input of conv2), maintained by the kernels that produce those tensors
+    const bool wha = amax && b.pk_q1 >= 0 && conv_wh_applies(P.fp32_convs, B, H, W, b.cin, b.cout);
+    const bool whb = amax && b.pk_q2 >= 0 && conv_wh_applies(P.fp32_convs, B, H, W, b.cout, b.cout);
     int rc = Wt > 0 ? dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
-                                    Wt, st, W, W, h2a ? amax : nullptr)
+                                    Wt, st, W, W, wha ? amax : nullptr)
                     : dwconv_launch(cur, params + b.dw_w, params + b.dw_b, cond, cond_stride, nullptr, 0, hbuf, B, b.cin, H,
-                                    W, st, 0, 0, h2a ? amax : nullptr);
+                                    W, st, 0, 0, wha ? amax : nullptr);
     if (rc) return rc;
     const bool wino = wino_enabled();
     ConvArgs c1{};
@@ -1084,13 +1072,9 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     // ... and the ones with several 8x32 items per CU its one-wave-per-SIMD form (weights shared by two n-tiles)
     const bool v4 = SINDDM_WINO_V4 && v3 && conv_wino4_applies(B, H, W, b.coblks);
     if (wha) {
-        c1.w3 = packed + b.pk_q1; c1.wsinv = packed + b.pk_qs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
+        c1.w3 = packed + b.pk_q1; c1.wsinv = packed + b.pk_qs1; c1.amax_in = amax; c1.amax_out = whb ? amax + 1 : nullptr;
         c1.bias = params + b.c1_b;
         rc = conv_wh_launch(c1, st);
-    } else if (h2a) {
-        c1.w3 = packed + b.pk_h1; c1.wsinv = packed + b.pk_hs1; c1.amax_in = amax; c1.amax_out = h2b ? amax + 1 : nullptr;
-        c1.bias = params + b.c1_b;
-        rc = conv_h2_launch(c1, st);
     } else if (v3 && b.pk_w1f >= 0) {
         c1.w3 = packed + b.pk_w1f; c1.nch3 = b.nchw1;
         rc = v4 ? conv_wino4_launch(c1, st) : conv_wino3_launch(c1, st);
@@ -1104,7 +1088,7 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         while (split < 8 && nwg * split < 2048 && b.cout % (split * 2) == 0) split *= 2;
         hipLaunchKernelGGL(conv3x3_c3_gelu_kernel, dim3((H * W + 255) / 256, B, split), dim3(256), 0, st, hbuf,
                            params + b.c1_w, params + b.c1_b, gbuf, c1.out_pre, H, W, b.cout, b.cout / split, Wt > 0 ? Wt : W,
-                           h2b ? amax + 1 : nullptr);
+                           whb ? amax + 1 : nullptr);
         SINDDM_LAUNCH_CHECK();
         rc = 0;
     } else {
@@ -1112,10 +1096,10 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         rc = conv_launch(c1, b.mt, st);
     }
     if (rc) return rc;
-    // conv2 on a binary16 kernel reads the running max of g (slot amax + 1): conv_wh / conv_h2 / the C_in = 3 kernel publish it
+    // conv2 on the binary16 kernel reads the running max of g (slot amax + 1): conv_wh / the C_in = 3 kernel publish it
     // from their epilogues, the fp32 kernels do not (dim = 80 / 240: block 1 has C_in = dim / 2, not a multiple of 16, so conv1
     // stays on an fp32 kernel while conv2 qualifies) -- one pass over g then
-    if (h2b && !(wha || h2a || (b.cin == 3 && c3 && !(v3 && b.pk_w1f >= 0) && !(wino && b.pk_wc1 >= 0 && b.cin % 4 == 0)))) {
+    if (whb && !(wha || (b.cin == 3 && c3 && !(v3 && b.pk_w1f >= 0) && !(wino && b.pk_wc1 >= 0 && b.cin % 4 == 0)))) {
         rc = amax_tensor_launch(gbuf, amax + 1, B, (long long)b.cout * H * W, st);
         if (rc) return rc;
     }
@@ -1140,9 +1124,6 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
         if (whb) {
             c2.w3 = packed + b.pk_q2; c2.wsinv = packed + b.pk_qs2; c2.amax_in = amax + 1;
             rc = conv_wh_launch(c2, st);
-        } else if (h2b) {
-            c2.w3 = packed + b.pk_h2; c2.wsinv = packed + b.pk_hs2; c2.amax_in = amax + 1;
-            rc = conv_h2_launch(c2, st);
         } else if (v3 && b.pk_w2f >= 0) {
             c2.w3 = packed + b.pk_w2f; c2.nch3 = b.nchw2;
             rc = v4 ? conv_wino4_launch(c2, st) : conv_wino3_launch(c2, st);
@@ -1159,8 +1140,8 @@ int block_forward(const NetPlan& P, int l, const float* params, const float* pac
     return rc;
 }
 
-bool wh_applies(int B, int H, int W, int cin, int cout) { return conv_wh_applies(B, H, W, cin, cout); }
-bool wh_enabled() { return SINDDM_CONV_WH && conv_wh_flag() != 0; }
+bool wh_applies(const NetPlan& P, int B, int H, int W, int cin, int cout) { return conv_wh_applies(P.fp32_convs, B, H, W, cin, cout); }
+bool wh_enabled() { return SINDDM_CONV_WH != 0; }
 int wh_conv(const ConvArgs& c, hipStream_t st) { return conv_wh_launch(c, st); }
 int wh_pack(const float* w, float* wsinv, void* img, int cin, int cout, int transpose, hipStream_t st) {
     return wh_pack_launch(w, wsinv, img, cin, cout, transpose, st);
@@ -1193,7 +1174,7 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
                      hipStream_t st, const TrainBufs* tb, const ChainStep* cs) {
     FwdBuffers fb{};
     float* xpad = nullptr;
-    float* amax = nullptr;       // eight running-max scalars per sample (conv_h2.h)
+    float* amax = nullptr;       // eight running-max scalars per sample (split16.h)
     if (tb) {
         fb.cond = tb->cond;
         amax = tb->amax;
@@ -1235,8 +1216,8 @@ int net_forward_impl(const NetPlan& P, const float* params, const float* packed,
         bool any = false;
         for (int l = 0; l < 4; ++l) {
             const BlockPlan& b = P.blk[l];
-            any = any || (b.pk_q1 >= 0 && conv_wh_applies(B, H, Wp, b.cin, b.cout)) || (b.pk_q2 >= 0 && conv_wh_applies(B, H, Wp, b.cout, b.cout)) ||
-                  (b.pk_h1 >= 0 && conv_h2_applies(B, H, Wp, b.cin, b.cout)) || (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout));
+            any = any || (b.pk_q1 >= 0 && conv_wh_applies(P.fp32_convs, B, H, Wp, b.cin, b.cout)) ||
+                  (b.pk_q2 >= 0 && conv_wh_applies(P.fp32_convs, B, H, Wp, b.cout, b.cout));
         }
         if (!any) amax = nullptr;
         else if (hipMemsetAsync(amax, 0, (size_t)B * AMAX_STRIDE * sizeof(float), st) != hipSuccess) return SINDDM_E_BADARG;
@@ -1447,7 +1428,7 @@ int sinddm_sample_chain2(const float* params, const float* packed, float* x, flo
                  items >= SINDDM_SPLIT_ITEMS_LO * ncu && (rounds * ncu - items) * 25 >= rounds * ncu;
     // (a batch whose 3x3 convs take the binary16 kernels stays whole: its halves could fall below their items-per-CU
     // threshold and run on the fp32 kernels -- the same chain would then round differently with and without a second stream)
-    if (split && (conv_wh_applies(B, H, fwd_pitch(p, W), p.dim, p.dim) || conv_h2_applies(B, H, fwd_pitch(p, W), p.dim, p.dim)))
+    if (split && conv_wh_applies(p.fp32_convs, B, H, fwd_pitch(p, W), p.dim, p.dim))
         split = false;
     // (the two halves carve their own cores behind the shared conditioning table: only if that really fits -- ADVICE r4)
     if (split && cond_region_bytes(p, B) + fwd_workspace_core(p, (B + 1) / 2, H, W) + fwd_workspace_core(p, B - (B + 1) / 2, H, W) > ws_bytes)
@@ -1614,18 +1595,8 @@ int sinddm_debug_infer_path(int dim, int B, int H, int W) {
     if (!p.ok || B <= 0 || H <= 0 || W <= 0) return SINDDM_E_BADARG;
     const BlockPlan& b = p.blk[2];                      // the dim -> dim block
     const int Wp = fwd_pitch(p, W);
-    if (b.pk_q2 >= 0 && conv_wh_applies(B, H, Wp, b.cout, b.cout)) return 8;
-    if (b.pk_h2 >= 0 && conv_h2_applies(B, H, Wp, b.cout, b.cout)) return 7;
+    if (b.pk_q2 >= 0 && conv_wh_applies(p.fp32_convs, B, H, Wp, b.cout, b.cout)) return 8;
     return conv3x3_path(b.cout, b.cout, b.coblks, B, H, Wp);
-}
-
-int sinddm_debug_set_h2(int on) {
-    int& f = conv_h2_flag();
-    int& g = conv_wh_flag();
-    const int prev = (f ? 1 : 0) | (g ? 2 : 0);
-    f = (on & 1) != 0;
-    g = (on & 2) != 0;
-    return prev;
 }
 
 int sinddm_prof_end3(int kind, double* ms_total, int64_t* launches, double* flops_total, double* exec_flops_total,

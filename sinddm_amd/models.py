@@ -124,6 +124,11 @@ class SinDDMNet(nn.Module):
     registration order (what the C ABI expects); gradients likewise, so the fused Adam/EMA
     kernel walks a single array."""
 
+    # per-call kernel option of the C ABI (include/sinddm_hip.h, SINDDM_DIM_FP32_CONVS): True keeps every 3x3 conv of this net's
+    # launches on the fp32 matrix pipe -- A/B measurements and parity tests (set it on an instance, or on the class for every
+    # net a test builds); no reference counterpart
+    fp32_convs = False
+
     def __init__(self, dim, out_dim=None, channels=3, with_time_emb=True, multiscale=False, device=None):
         super().__init__()
         if not with_time_emb or not multiscale:
@@ -291,9 +296,14 @@ class SinDDMNet(nn.Module):
             t_dev = t_dev.to(device=x.device, dtype=torch.int64).contiguous()
         _lib.check(lib.sinddm_net_forward(_lib.ptr(self._flat), _lib.ptr(packed), _lib.ptr(x),
                                           _lib.ptr(t_dev) if t_dev is not None else None, int(t_host),
-                                          float(scale), _lib.ptr(out), self.dim, B, H, W, ws.data_ptr(),
+                                          float(scale), _lib.ptr(out), self.dim_arg, B, H, W, ws.data_ptr(),
                                           ws.numel(), _lib.stream_ptr(x.device)), "sinddm_net_forward")
         return out
+
+    @property
+    def dim_arg(self) -> int:
+        """The `dim` argument of the launching C-ABI calls: the width + this net's option bits."""
+        return self.dim | (_lib.DIM_FP32_CONVS if self.fp32_convs else 0)
 
     def forward(self, x, time, scale=None):
         """eps = net(x, time, scale) -- same call signature as the reference (models.py:134)."""
@@ -651,7 +661,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
         in_alt = C.c_int(0)
         # (the second stream lets the library run coarse scales as two overlapping half-batches; same numbers either way)
         _lib.check(lib.sinddm_sample_chain2(_lib.ptr(net.flat_params), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(x_alt),
-                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim, B, H, W,
+                                            _lib.ptr(eps), _lib.ptr(xt), coefs, tl, n, float(s), seed, 0, net.dim_arg, B, H, W,
                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr(x.device),
                                             _aux_stream(x.device) if self.two_streams else None, C.byref(in_alt)),
                    "sinddm_sample_chain2")

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _header_symbols():
         assert hasattr(lib, name), name
-    assert lib.sinddm_abi_version() == 2
+    assert lib.sinddm_abi_version() == 3
     assert not _lib.missing_symbols()
 
 

@@ -121,6 +121,20 @@ def test_full_chain_c3_t1000_batch64_golden(golden):
     assert max(iso) < 1e-4, iso
 
 
+def test_full_chain_c5_scale_mul_2_4_batch32_golden(golden):
+    """G19: C5 (marinabaysands, 5 scales, T = 1000) sampled with --scale_mul 2 4 -- the odd geometry 92x276 ... 364x1092 of
+    reference trainer.py:247-252 / models.py:549-568 (int() truncation of the stretched sizes, bilinear upsample between
+    stretched scales) -- at its benchmarked global batch of 32: every scale runs on conv_wh.  2 521 chained evaluations
+    against the REFERENCE's images."""
+    g = golden("g19_chain_c5_mul24.npz")
+    assert tuple(g["scale_mul"]) == (2, 4)
+    cum, iso = _chain_vs_fixture("C5", g, 32, [8, 8, 8, 8, 8], scale_mul=(2, 4))
+    print("C5 x (2,4) chain at B=32, rel-L2 per scale (cumulative):", ["%.2e" % e for e in cum])
+    print("C5 x (2,4) chain at B=32, rel-L2 per scale (restarted from the reference's previous scale):", ["%.2e" % e for e in iso])
+    assert max(cum) < 1e-4, cum
+    assert max(iso) < 1e-4, iso
+
+
 def _c1_trainer(tmp_path, golden, dim=160):
     from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
     from sinddm_amd.trainer import MultiscaleTrainer

@@ -216,7 +216,7 @@ def test_large_batch_index_range():
     assert rel_l2(y[-2:].cpu(), y_tail.cpu()) < 2e-6 and rel_l2(y[:2].cpu(), y_head.cpu()) < 2e-6
     assert torch.equal(y[-16:], y_sub)
     del y_sub
-    prev = lib.sinddm_debug_set_h2(0)
+    net.fp32_convs = True                      # the same launches on the fp32 matrix pipe (SINDDM_DIM_FP32_CONVS)
     try:
         with torch.no_grad():
             y0 = net(x, t, scale=5)
@@ -225,7 +225,7 @@ def test_large_batch_index_range():
         assert torch.equal(y0[-2:], y0_tail) and torch.equal(y0[:2], y0_head)
         assert rel_l2(y.cpu()[::21], y0.cpu()[::21]) < 2e-6
     finally:
-        lib.sinddm_debug_set_h2(prev)
+        net.fp32_convs = False
 
 
 @pytest.mark.parametrize("dim", [20, 28, 10])

@@ -321,10 +321,10 @@ def test_net_backward_binary16_convs_vs_float64():
     t = torch.tensor([731, 12, 5, 999, 340, 77, 501, 888])
 
     def run(mode):
-        prev = lib.sinddm_debug_set_h2(mode)
         try:
-            assert lib.sinddm_debug_train_path(dim, B, H, W) == (8 if mode == 3 else 4)
+            assert lib.sinddm_debug_train_path(dim | (0 if mode == 3 else _lib.DIM_FP32_CONVS), B, H, W) == (8 if mode == 3 else 4)
             net = SinDDMNet(dim=dim, multiscale=True, device=DEV).to(DEV)
+            net.fp32_convs = mode != 3
             net.load_state_dict(closed_form_state_dict(dim))
             net.bind_grads()
             net.flat_grads.zero_()
@@ -335,7 +335,7 @@ def test_net_backward_binary16_convs_vs_float64():
             return (y.detach().cpu().double(), xd.grad.cpu().double(),
                     {n: p.grad.cpu().double().clone() for n, p in net.named_parameters()})
         finally:
-            lib.sinddm_debug_set_h2(prev)
+            pass
 
     y_h, gx_h, g_h = run(3)
     y_f, gx_f, g_f = run(0)

@@ -21,13 +21,13 @@ DEV = "cuda:0"
 
 @pytest.fixture(autouse=True)
 def _fp32_mfma_path():
-    """Inference launches of these shapes default to conv_h2 (tests/test_gpu_h2.py); conv_wino4 stays the kernel of the
+    """Inference launches of these shapes default to conv_wh (tests/test_gpu_h2.py); conv_wino4 stays the kernel of the
     training forward / data gradients and of the switch-off path: keep it under test."""
-    from sinddm_amd import _lib
-    lib = _lib.load()
-    prev = lib.sinddm_debug_set_h2(0)
+    from sinddm_amd.models import SinDDMNet
+    prev = SinDDMNet.fp32_convs
+    SinDDMNet.fp32_convs = True        # (class attribute: every net these tests build launches with SINDDM_DIM_FP32_CONVS)
     yield
-    lib.sinddm_debug_set_h2(prev)
+    SinDDMNet.fp32_convs = prev
 
 
 def _path(B, H, W):

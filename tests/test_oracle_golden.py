@@ -222,6 +222,24 @@ def test_g18_chain_c3_scale1_restart(golden):
     assert rel_l2(x, g["out_s1"]) < 1e-5
 
 
+def test_g19_chain_c5_scale_mul_bookkeeping(golden):
+    """G19 (the reference's C5 chain sampled with scale_mul = (2, 4): trainer.py:247-252, models.py:549-568): the sizes the
+    reference actually sampled at -- int() truncation of the stretched pyramid sizes -- are what the oracle's size selection
+    gives, and the draw count is 1 + sum(ideal) + (n - 1).  The images themselves are the GPU test's job."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g19_chain_c5_mul24.npz")
+    c5 = meta["C5"]
+    sched = _sched(meta, "C5")
+    assert sched["num_timesteps_ideal"] == list(g["ideal"]) == [1000, 544, 426, 322, 229]
+    assert int(g["plan_len"]) == 1 + sum(sched["num_timesteps_ideal"]) + 4
+    sizes = [tuple(s) for s in c5["image_sizes_hw"]]
+    want = [(92, 276), (130, 388), (182, 548), (258, 776), (364, 1092)]          # SURVEY.md 8(d), C5
+    for s, hw in enumerate(sizes):
+        got = O.scale_size(sizes, len(sizes), c5["scale_factor"], s, scale_mul=(2, 4))
+        assert tuple(got) == want[s] == tuple(g[f"out_s{s}"].shape[2:]), (s, got)
+        assert np.isfinite(g[f"out_s{s}"]).all()
+
+
 def test_adam_and_lr_restatement():
     torch.manual_seed(0)
     p = torch.randn(50)

@@ -26,8 +26,9 @@
 // Replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] / nn.Conv2d(dim_out, dim_out, 3, padding=1) [+ residual] of
 // SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80).
 #pragma once
-#include "conv_mfma.h"
-#include "conv_wino2.h"
+// ARCHIVED (round 6): not part of libsinddm_hip.so.  The helpers it shared with conv_wh.h live in csrc/split16.h; to build it
+// again include this file behind split16.h and restore the dispatch of round 5 (git show 6674de8:sinddm_amd/csrc/sinddm_fwd.hip).
+#include "../../sinddm_amd/csrc/split16.h"
 
 namespace sinddm {
 
