@@ -11,16 +11,20 @@
 //
 // Work item = 8x32 pixels (32 tiles of 2x4: tile row tr 0..3, tile column tc 0..7) x 80 output channels.  One persistent
 // workgroup of 8 waves (two per SIMD) per CU.  Per 16-channel chunk:
-//   * raw halo tile (16 x 10 x 34 fp32) global -> LDS by buffer_load ... lds (out-of-image = out-of-range offset = zeros),
-//     double buffered, two chunks ahead;
-//   * T phase (the two service waves): task = (tile, channel pair, half of the vertical frequencies): 2-D input transform as
-//     packed fp32 on the channel pair, x 2^s (per-sample scale from the tensor's running max), split, written to LDS as the A
-//     fragments of the 24 frequency GEMMs: [f][tile group of 16][k group: piece x channel half][tile][8 x f16] (48 KB, double buffered);
+//   * raw halo tile (16 x 10 x 40 fp32) by plain 16-byte buffer loads into 64 registers of the two service waves (out-of-image =
+//     out-of-range offset = zeros), written to LDS one iteration later: the registers are the look-ahead buffer;
+//   * T phase (the two service waves): lane = (tile, channel quad) does all four vertical frequencies of its tile: the 4 x 6 patch
+//     from one ds_read_b128 per (channel, row) + DPP row shifts for the two outer columns (round 6; bank-conflict-free lane map),
+//     2-D input transform as packed fp32 on channel pairs, x 2^s (per-sample scale from the tensor's running max), split, written
+//     to LDS as the A fragments of the 24 frequency GEMMs: [f][tile group of 16][k group: piece x channel half][tile][8 x f16]
+//     (48 KB, double buffered);
 //   * M phase (waves 0..5): wave w owns frequencies 4w .. 4w+3 of all 32 tiles x 80 channels (4 x 2 x 5 accumulator tiles =
 //     160 registers); its U fragments come straight from L2 into registers one frequency (5 column tiles) ahead.
-//   One barrier per chunk.
-// Epilogue: per 16-channel column tile the waves exchange their frequencies through LDS ([f][co][tile], the V buffers);
-// thread = (tile, channel) gathers 24 values, inverse transform A^T M A, scale, bias, GELU / GELU' / residual, 16-byte stores.
+//   One LDS-only barrier per chunk.  The chunks of a workgroup's items form one stream (round 6): during an item's last multiply
+//   the service waves already produce the next item's first chunk.
+// Epilogue: per 16-channel column tile the waves exchange their frequencies through LDS ([f][co][tile], ONE buffer placed beside
+// the V buffer that holds the next item's first chunk); thread = (tile, channel) gathers 24 values, inverse transform A^T M A,
+// scale, bias, GELU / GELU' / residual, 16-byte stores.
 //
 // Replaces nn.Conv2d(dim, dim_out, 3, padding=1) [+ GELU] / nn.Conv2d(dim_out, dim_out, 3, padding=1) [+ residual] of
 // SinDDMConvBlock (reference SinDDM/models.py:63-65,79-80) -- inference, training forward and (with transposed, tap-flipped weight
@@ -46,6 +50,9 @@ __device__ __forceinline__ void wh_static_for(F&& f) {
 #ifndef WH_ABL
 #define WH_ABL 0
 #endif
+#ifndef WH_MIXLO
+#define WH_MIXLO 1             // lo piece by v_fma_mixlo/hi_f16 (1) or v_fma_mix_f32 x 2 + v_cvt_pk_f16_f32 (0)
+#endif
 #ifndef WH_NT
 #define WH_NT 6                // bit 0: raw-tile loads non-temporal (measured: +8 %, the co blocks' sharing in L2 is lost), bit 1: epilogue residual loads, bit 2: output stores -- of tensors beyond the 256 MB last-level cache only (C3: -1.2 %, C2: +0.6 % without that rule)
 #endif
@@ -63,13 +70,17 @@ constexpr int WH_RAW = 16 * WH_PS * 4;         // bytes of one raw buffer: 26 11
 constexpr int WH_V = 24 * 2 * 64 * 16;         // bytes of one V buffer: 49 152
 constexpr int WH_XS = 36;                      // tile stride of the epilogue's exchange rows (32 + 4: conflict-free 16-byte writes)
 constexpr int WH_X = 24 * 16 * WH_XS * 4;      // one exchange buffer [f][co][tile]: 55 296
-constexpr int WH_DUMMY = 2 * WH_RAW + 2 * WH_X; // 256 bytes per service wave: landing area of the L2-warming requests
-constexpr int WH_LDS = WH_DUMMY + 512;         // 163 328 (the V buffers are the first 98 304 bytes behind the raw buffers)
-static_assert(2 * WH_X >= 2 * WH_V && WH_LDS <= 160 * 1024, "LDS of a gfx950 CU");
+// LDS map (round 6): [raw tile 26 112][region of 137 728: V buffer A at 0, V buffer B at its end; the epilogue's ONE exchange
+// buffer lies at 0 or behind buffer A -- wherever the V fragments of the NEXT item's first chunk are not (they are written
+// during this item's last multiply)]
+constexpr int WH_LDS = 160 * 1024;
+constexpr int WH_REGION = WH_LDS - WH_RAW;     // 137 728
+constexpr int WH_VB = WH_REGION - WH_V;        // V buffer B: 88 576
+static_assert(WH_X <= WH_VB && WH_V + WH_X <= WH_REGION && WH_VB % 16 == 0, "exchange buffer beside either V buffer");
 constexpr int WH_TARGET_EXP = 10;              // scaled max |x| in [2^10, 2^11): |V| <= 20 max |x| stays below 65 504
 constexpr int WH_COB = 80;                     // output channels per item
 
-inline bool wh_shape_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout % WH_COB == 0; }
+inline bool wh_shape_ok(int cin, int cout) { return cin >= 32 && cin % 16 == 0 && cout % WH_COB == 0; }   // (>= 2 chunks: the chunk stream looks two ahead)
 // f16 elements of the packed image: [co block][chunk][f 24][n 5][piece 2][k half 2][co 16][8]
 inline long long wh_image_halfs(int cin, int cout) { return (long long)(cout / WH_COB) * (cin / 16) * 24 * 5 * 512; }
 
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* const sbytes = reinterpret_cast<unsigned char*>(smem);
     unsigned char* const sRaw = sbytes;
-    unsigned char* const sV = sbytes + 2 * WH_RAW;
+    unsigned char* const sV = sbytes + WH_RAW;
     const unsigned lds0 = (unsigned)(size_t)(lds_f*)smem;
 
     const int tid = threadIdx.x;
@@ -314,25 +325,36 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
         stage_offsets(cur, svoff);
         stage_load(in_rsrc(cur.b), svoff, 0);
     }
+    // operand scale of an item: 2^s from the sample's running max, times the item's dither sign.
+    // Sign dither: v_mfma_f32_16x16x32_f16 rounds its sum with a small bias toward -infinity whatever the signs (measured,
+    // tools/ubench/mfma_bias.hip: -0.008 ulp of the accumulator per instruction, 1.4 % of the rms rounding error).  Invisible per
+    // element, but coherent over a plane: a sum over 46 000 pixels amplifies it 215-fold against the white part (the bias
+    // and condition-path gradients of training are such sums).  Items of neighbouring tiles therefore run with opposite
+    // signs of V (folded into the exact power-of-two scales): the bias alternates in the image and cancels in the sums.
+    auto item_scale = [&](const Item& it, float& sxo, float& inv) {
+        const int xs = p.amax_in ? wh_shift_for(p.amax_in[(size_t)it.b * AMAX_STRIDE], WH_TARGET_EXP) : 0;
+        const float sg = (((it.x0 >> 5) + (it.y0 >> 3) + it.b) & 1) ? -1.0f : 1.0f;
+        sxo = sg * h2_pow2(xs);
+        inv = sg * h2_pow2(-xs);
+    };
+    // The chunks of a workgroup's items form ONE stream (round 6): while the multiplying waves run an item's LAST chunk the
+    // service waves already stage and transform the NEXT item's first chunk, into the V buffer that chunk would take anyway
+    // (running chunk parity `g`); the epilogue exchanges through one buffer placed beside it.  Only a workgroup's first item has
+    // a prologue (round 5: every item waited ~6 000 cycles for its first transform: 7-10 % of an item).
+    int g = 0;                                               // chunks this workgroup has run so far: chunk k of the stream -> V buffer k & 1
+    auto vbuf = [&](int k) { return sV + ((k & 1) ? WH_VB : 0); };
     for (int j = 0;; ++j) {
         const Item nxt = decode(j + 1);
         const int cb = cur.cb, b = cur.b, y0 = cur.y0, x0 = cur.x0;
-
-        const int xs = p.amax_in ? wh_shift_for(p.amax_in[(size_t)b * AMAX_STRIDE], WH_TARGET_EXP) : 0;
-        // Sign dither: v_mfma_f32_16x16x32_f16 rounds its sum with a small bias toward -infinity whatever the signs (measured,
-        // tools/ubench/mfma_bias.hip: -0.008 ulp of the accumulator per instruction, 1.4 % of the rms rounding error).  Invisible per
-        // element, but coherent over a plane: a sum over 46 000 pixels amplifies it 215-fold against the white part (the bias
-        // and condition-path gradients of training are such sums).  Items of neighbouring tiles therefore run with opposite
-        // signs of V (folded into the exact power-of-two scales): the bias alternates in the image and cancels in the sums.
-        const float sg = (((x0 >> 5) + (y0 >> 3) + b) & 1) ? -1.0f : 1.0f;
-        const float sx = sg * h2_pow2(xs), inv_sx = sg * h2_pow2(-xs);
-        const f32x2 sx2{sx, sx};
+        float sx, inv_sx;
+        item_scale(cur, sx, inv_sx);
 
         const __amdgpu_buffer_rsrc_t rsin = in_rsrc(b);
 
         // ---- T phase of one chunk (service waves): raw buffer -> V buffer ----
-        auto transform = [&](const unsigned char* raw, unsigned char* vb) {
+        auto transform = [&](const unsigned char* raw, unsigned char* vb, float sxv) {
             if (WH_ABL & 2) return;
+            const f32x2 sx2{sxv, sxv};
             const unsigned char* rpB = raw + t_rdB;
             const unsigned char* rpE = raw + t_rdE;
             unsigned char* wp = vb + t_wr0;
@@ -378,8 +400,13 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
                         hi[pr][j] = __builtin_convertvector(sc, h16x2);
                         // (remainder by v_fma_mix_f32 with the binary16 piece as an operand: v * sx is exact, so
                         // fma(v, sx, -hi) = sc - hi exactly; one instruction per value instead of a conversion and half a packed subtract)
+#if WH_MIXLO
                         // ... and rounded to binary16 by the same instruction (v_fma_mixlo_f16 / v_fma_mixhi_f16: one rounding of the exact remainder)
-                        lo[pr][j] = h16x2{(_Float16)__builtin_fmaf(v[j].x, sx, -(float)hi[pr][j].x), (_Float16)__builtin_fmaf(v[j].y, sx, -(float)hi[pr][j].y)};
+                        lo[pr][j] = h16x2{(_Float16)__builtin_fmaf(v[j].x, sxv, -(float)hi[pr][j].x), (_Float16)__builtin_fmaf(v[j].y, sxv, -(float)hi[pr][j].y)};
+#else
+                        const f32x2 rem{__builtin_fmaf(v[j].x, sxv, -(float)hi[pr][j].x), __builtin_fmaf(v[j].y, sxv, -(float)hi[pr][j].y)};
+                        lo[pr][j] = __builtin_convertvector(rem, h16x2);
+#endif
                     }
                 }
 #pragma unroll
@@ -474,52 +501,60 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
         // ---- the two roles run their own loops (same number of barriers): nothing of the one is live in the other ----
         WH_SEG(0);
         if constexpr (service) {
-            // the registers hold this wave's planes of chunk 0 (loaded during the previous item's epilogue or in front of the
-            // loop): to LDS, chunk 1 on its way, V(0)
-            stage_write(sRaw);
-            if (nch > 1) stage_load(rsin, svoff, 1);
-            WH_SEG(1);
-            transform(sRaw, sV);
-            wh_barrier();
+            const __amdgpu_buffer_rsrc_t rsnx = in_rsrc(nxt.ok ? nxt.b : b);
+            float sxn = 0.f, inv_n = 0.f;
+            if (nxt.ok) item_scale(nxt, sxn, inv_n);
+            if (j == 0) {
+                // the workgroup's first item: the registers hold this wave's planes of chunk 0 -> LDS, the stream's next chunk on
+                // its way, V(0)
+                stage_write(sRaw);
+                if (nch > 1) stage_load(rsin, svoff, 1);
+                else if (nxt.ok) { stage_offsets(nxt, svoff); stage_load(rsnx, svoff, 0); }
+                WH_SEG(1);
+                transform(sRaw, vbuf(g), sx);
+                wh_barrier();
+            }
             WH_SEG(2);
             for (int c = 0; c < nch; ++c) {
-                // chunk c + 1 (loaded one iteration ago) goes to LDS -- the one raw buffer: only this wave reads these planes, and
-                // it has finished T(c) --, chunk c + 2 is requested, chunk c + 1 transformed while the others multiply chunk c
-                if (c + 1 < nch) {
+                // stream chunk k + 1 (loaded one iteration ago) goes to LDS -- the one raw buffer: only this wave reads these
+                // planes, and it has finished T(k) --, chunk k + 2 is requested, chunk k + 1 transformed while the others multiply
+                // chunk k.  Behind this item's last chunk the stream continues with the next item's chunks 0 and 1.
+                if (c + 1 < nch || nxt.ok) {
                     stage_write(sRaw);
                     if (c + 2 < nch) stage_load(rsin, svoff, c + 2);
+                    else if (nxt.ok) {
+                        if (c + 2 == nch) stage_offsets(nxt, svoff);
+                        if (c + 2 == nch || nch > 1) stage_load(rsnx, svoff, c + 2 - nch);
+                    }
                     if (c == 3) WH_SEG(24);
-                    transform(sRaw, sV + ((c + 1) & 1) * WH_V);
+                    transform(sRaw, vbuf(g + c + 1), c + 1 < nch ? sx : sxn);
                     if (c == 3) WH_SEG(25);
                 }
                 wh_barrier();
                 if (c < 12) WH_SEG(3 + c);
             }
             ep_operands();
-            // the next item's first chunk travels during this item's epilogue
-            if (nxt.ok) {
-                stage_offsets(nxt, svoff);
-                stage_load(in_rsrc(nxt.b), svoff, 0);
-            }
         } else {
             wh_static_for<10>([&](auto SL) {
                 constexpr int sl = decltype(SL)::value;
                 load_u(0, sl / 5, sl % 5, sl);
             });
             WH_SEG(1);
-            wh_barrier();
+            if (j == 0) wh_barrier();
             WH_SEG(2);
             for (int c = 0; c < nch; ++c) {
-                multiply(c, sV + (c & 1) * WH_V);
+                multiply(c, vbuf(g + c));
                 if (c == 3) WH_SEG(25);
                 wh_barrier();
                 if (c < 12) WH_SEG(3 + c);
             }
             ep_operands();
         }
+        g += nch;
         WH_SEG(16);
 
-        // ---- epilogue: per column tile n the multiplying waves hand their frequencies over through LDS (the V buffers) ----
+        // ---- epilogue: per column tile n the multiplying waves hand their frequencies over through LDS: ONE exchange buffer,
+        // beside the V buffer that already holds the next item's first chunk (buffer g & 1) ----
         // writer: acc[fi][mg][n] = D[tile = mg*16 + 4 kq + r][co = l16]  ->  X[f][co][tile]
         // reader: thread = (tile t = tid & 31, co16 = tid >> 5)
         const int e_wr = ((f0 * 16 + l16) * WH_XS + 4 * kq) * 4;    // X[f][co][tile (stride 36)] byte offsets: writer (f0, co = l16, tile 4 kq)
@@ -528,7 +563,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
         WH_SEG(17);
         wh_static_for<5>([&](auto NN) {
             constexpr int n = decltype(NN)::value;
-            unsigned char* X = sV + (n & 1) * WH_X;
+            unsigned char* X = sV + ((g & 1) ? 0 : WH_V);
             if constexpr (!service) {
 #pragma unroll
                 for (int fi = 0; fi < 4; ++fi)
@@ -541,6 +576,7 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
             float m[24];
 #pragma unroll
             for (int f = 0; f < 24; ++f) m[f] = *reinterpret_cast<const float*>(X + e_rd + f * (16 * WH_XS * 4));
+            wh_barrier();                                 // (every wave holds its 24 values: the buffer is free for the next pass / the next item's V)
             // vertical A^T (F(2,3)): y0 = m0 + m1 + m2, y1 = m1 - m2 - m3
             float q[2][6];
 #pragma unroll
@@ -582,7 +618,6 @@ __global__ __launch_bounds__(512) void conv_wh_kernel(ConvArgs p, int items_per_
             }
         });
         if (p.amax_out) amax_publish(amax, p.amax_out + (size_t)b * AMAX_STRIDE);
-        wh_barrier();                                     // (the next item's T(0) writes the V buffers)
         WH_SEG(23);
         if (!nxt.ok) break;
         cur = nxt;

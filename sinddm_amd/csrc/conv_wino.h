@@ -21,19 +21,13 @@
 #pragma once
 #include "conv_mfma.h"
 #include "conv1x1.h"
-// SINDDM_WINO_V2 = 1 (default): conv_wino_launch() runs the second-generation kernel of conv_wino2.h (two 4-wave
-// workgroups per CU, wave = frequency row); 0 keeps this file's 16-wave kernel (A/B builds).  The packed weight
-// layout (pack kind 3) follows the same switch.
-#ifndef SINDDM_WINO_V2
+// conv_wino_launch() runs the second-generation kernel of conv_wino2.h (two 4-wave workgroups per CU, wave = frequency row).
+// (The first-generation 16-wave kernel and its -DSINDDM_WINO_V2=0 build are archived: tools/variants/conv_wino_gen1.h and
+// `git show 6674de8:sinddm_amd/csrc/conv_wino.h` -- product sources include nothing from tools/.)
 #define SINDDM_WINO_V2 1
-#endif
 #include "conv_wino2.h"
 
 namespace sinddm {
-
-#if !SINDDM_WINO_V2
-#include "../../tools/variants/conv_wino_gen1.h"     // (archived first-generation kernel: variant builds only)
-#endif
 
 inline int device_cu_count() {
     static int n = [] {
@@ -46,51 +40,10 @@ inline int device_cu_count() {
 }
 
 inline int conv_wino_launch(const ConvArgs& a_in, int mt, hipStream_t st) {
-#if SINDDM_WINO_V2
-    // (the second-generation kernel stages a wave's four channel planes of a chunk through one descriptor; the packed
-    // Winograd image has ITS layout, so the first-generation kernel below must not see it: callers route convs with
+    // (the kernel stages a wave's four channel planes of a chunk through one descriptor: callers route convs with
     // C_in % 4 != 0 -- dim = 10, 20, 28 ... -- to the direct kernel)
     if (a_in.Cin % 4 != 0) return SINDDM_E_BADSHAPE;
     return conv_wino2_launch(a_in, mt, st);
-#else
-    ConvArgs a = a_in;
-    const int ntr = wino_ntr();
-    ConvProfiler& prof = conv_profiler();
-    const bool rec = prof.on && prof.used < ConvProfiler::MAXREC;
-    if (rec) {
-        while (prof.created <= prof.used) {
-            (void)hipEventCreate(&prof.ev[2 * prof.created]);
-            (void)hipEventCreate(&prof.ev[2 * prof.created + 1]);
-            ++prof.created;
-        }
-        (void)hipEventRecord(prof.ev[2 * prof.used], st);
-    }
-    const int TH = 2 * ntr;
-    a.tilesX = (a.W + WN_TW - 1) / WN_TW;
-    a.tilesY = (a.H + TH - 1) / TH;
-    a.ntiles = a.B * a.tilesX * a.tilesY;
-    a.tiles_per_xcd = (a.ntiles + 7) / 8;
-    // persistent launch: one 16-wave workgroup per CU (its registers and LDS fill the CU), each walking its
-    // share of the XCD's work items
-    const int ipx = a.tiles_per_xcd * a.coblks;                  // work items per XCD
-    int wpx = device_cu_count() / 8;                             // workgroups per XCD
-    if (wpx < 1) wpx = 1;
-    if (wpx > ipx) wpx = ipx;
-    const unsigned grid = (unsigned)(wpx * 8);
-    switch (mt) {
-        case 5: conv_wino_launch_t<5>(a, grid, ipx, wpx, ntr, st); break;
-        case 2: conv_wino_launch_t<2>(a, grid, ipx, wpx, ntr, st); break;
-        case 1: conv_wino_launch_t<1>(a, grid, ipx, wpx, ntr, st); break;
-        default: return SINDDM_E_BADSHAPE;
-    }
-    if (rec) {
-        (void)hipEventRecord(prof.ev[2 * prof.used + 1], st);
-        const double fl = 2.0 * a.B * a.H * a.W * (double)a.Cout * 9.0 * a.Cin;   // algorithmic (direct-conv) FLOPs
-        prof.note(1, fl, fl * (16.0 / 36.0), 1);
-    }
-    SINDDM_LAUNCH_CHECK();
-    return 0;
-#endif
 }
 
 inline bool wino_enabled() { return SINDDM_CONV_WINO != 0; }

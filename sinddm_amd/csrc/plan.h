@@ -11,7 +11,7 @@ constexpr int TIME_DIM = 32;   // models.py:101
 constexpr int CHANNELS = 3;
 
 // conv_wh.h (Winograd F(2x4) with binary16 hi/lo frequency GEMMs): packed image [co block of 80][chunk of 16 ci][f 24][n 5][piece][k half][co 16][8 x f16]
-inline bool wh_plan_ok(int cin, int cout) { return cin >= 16 && cin % 16 == 0 && cout % 80 == 0; }
+inline bool wh_plan_ok(int cin, int cout) { return cin >= 32 && cin % 16 == 0 && cout % 80 == 0; }
 inline long long wh_plan_halfs(int cin, int cout) { return (long long)(cout / 80) * (cin / 16) * 24 * 5 * 512; }
 
 struct BlockPlan {

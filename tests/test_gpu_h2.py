@@ -133,7 +133,7 @@ def test_fused_chain_h2_vs_winograd(h2_switch):
 
 
 # ---- round 6: the gate on non-benign weights and batches (VERDICT r5 "what's weak" 1c) --------------------------------
-def _gate(net, sd, x, t, scale, idx, label, factor=1.5):
+def _gate(net, sd, x, t, scale, idx, label, factor=1.5, tol32=1e-5):
     """conv_wh's error against float64 <= factor x the error of fp32 arithmetic on the same inputs: the larger of the fp32
     oracle's (direct convolution, torch CPU) and the library's fp32-MFMA Winograd path's (F(2x4) in fp32 -- what rounds 3-4
     shipped; a Winograd transform in fp32 has its own, weight-dependent amplification that the direct form does not)."""
@@ -149,7 +149,7 @@ def _gate(net, sd, x, t, scale, idx, label, factor=1.5):
         e_k, e_w, e_32 = rel_l2(got[i:i + 1], ref64), rel_l2(got_w[i:i + 1], ref64), rel_l2(ref32, ref64)
         print(f"[{label}] sample {i}: vs float64  conv_wh {e_k:.3e}  fp32-MFMA Winograd {e_w:.3e}  fp32 oracle {e_32:.3e}")
         assert e_k <= factor * max(e_32, e_w), (label, i, e_k, e_w, e_32)
-        assert rel_l2(got[i:i + 1], ref32) < 1e-5, label          # the tolerance every net-forward parity test uses
+        assert rel_l2(got[i:i + 1], ref32) < tol32, label          # (1e-5: the tolerance every net-forward parity test uses)
         worst = max(worst, e_k / max(e_32, e_w))
     return worst
 
@@ -256,4 +256,6 @@ def test_conv2_on_binary16_behind_an_fp32_conv1(dim):
     net = _net(dim, sd)
     x = hash_randn((B, 3, H, W), 780) * 0.9
     t = torch.tensor([(53 * (i + 3)) % 1000 for i in range(B)], dtype=torch.long)
-    _gate(net, sd, x, t, 1, [0, B - 1], f"dim {dim}")
+    # (activations of ~4 000 put every fp32 evaluation 1e-5 from float64 -- the depthwise conv and the 1x1 projections cancel large
+    # terms --, so two fp32 results may differ by 2e-5: the gate is the ratio)
+    _gate(net, sd, x, t, 1, [0, B - 1], f"dim {dim}", tol32=4e-5)

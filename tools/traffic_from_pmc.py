@@ -29,6 +29,10 @@ def per_launch(prefix, ps, counter):
 
 
 def main(prefix, tag):
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sinddm_amd import build as _build
+    lib_hash = _build.stamp()          # what the passes ran: bench.py flags the record stale when the library changes
     alg = {"c2": 16 * 186 * 248, "c3": 64 * 411 * 512}          # pixels per launch
     # algorithmic bytes of the seven Winograd launches of a step: input once + output once, fp32
     chans = [(80, 80), (80, 160), (160, 160), (160, 160), (160, 160), (160, 80), (80, 80)]
@@ -40,7 +44,8 @@ def main(prefix, tag):
             continue
         algb = sum(4.0 * (ci + co) * alg[cfg] for ci, co in chans) / len(chans)
         out[cfg.upper()] = {
-            "kernel": "the seven 3x3 launches of a step pooled (conv_wh_kernel / conv_h2_kernel / conv_wino*_kernel, whichever ran)", "launches_sampled": n,
+            "kernel": "the seven 3x3 launches of a step pooled (conv_wh_kernel / conv_wino*_kernel, whichever ran)", "launches_sampled": n,
+            "lib_source_sha256": lib_hash,
             "source": f"profiles/{tag}_pmc_{cfg}_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, KiB)",
             "fetch_size_bytes_raw": fetch * 1024, "write_size_bytes_raw": write * 1024,
             "fetch_size_bytes_x2": 2 * fetch * 1024,

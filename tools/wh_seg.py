@@ -28,7 +28,7 @@ try:
     names = ["80->80", "80->160 GELU", "160->160", "160->160 GELU", "160->160", "160->80 GELU", "80->80"]
     for jl in range(7):
         r = a[(7 + jl) % 8]
-        print(f"== launch {jl} {names[jl]}  (units: s_memtime ticks = 10 ns)")
+        print(f"== launch {jl} {names[jl]}  (units: shader clock cycles)")
         for w in (0, 5, 6):
             t = r[:, w, :]
             ok = (t[:, 23] > 0) & (t[:, 0] > 0)
