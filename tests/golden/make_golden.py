@@ -25,6 +25,10 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g12_model-1.pt     a checkpoint WRITTEN BY the reference trainer's save() after 3 train() steps (dim=16)
   g12_ckpt.npz       what the reference computes from that checkpoint (EMA net forward, one p_sample step)
   g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
+  g18_chain_c3.npz   full C3 chain (6 scales, T=1000, finest 411x512: 2 551 evaluations -- the workload bench.py is quoted on), hash noise
+                     (`python tests/golden/make_golden.py g18`, ~10 CPU-minutes)
+  g19_chain_c5_mul24.npz  full C5 chain sampled with scale_mul=(2,4) (92x276 ... 364x1092: 2 521 evaluations), hash noise
+                     (`... g19`, ~40 CPU-minutes)
   g16_clip_roi.npz    trainer.clip_roi_sampling (trainer.py:412-468) with the synthetic score: ROI ascent + 5 reverse steps
   g15_clip_guided.npz CLIP-guided p_sample steps (models.py:367-431) with a SYNTHETIC differentiable score in place of
                      CLIP (clip/ is out of scope): mask creation, sub-iterations, lambda blending across steps, dim=32
@@ -450,7 +454,7 @@ def g_chain(cfg_name, out_name, scale_mul=(1, 1)):
     """Full chain of a headline config from the REFERENCE: T=1000, B=1, dim=160, hash noise -- G14's recipe for any
     config of g11_img_scales.json.  G18 = C3 (6 scales, finest 411x512: 2 551 chained evaluations, the workload bench.py
     is quoted on); G19 = C5 with scale_mul=(2, 4) (the odd 364x1092 geometry, reference sample_via_scale size selection
-    models.py:549-568 with custom_sample=False).  Stores the per-scale outputs as float16 deltas?  No: float32, compressed."""
+    models.py:549-568 with custom_sample=False).  Stores the per-scale outputs (float32, compressed)."""
     with open(os.path.join(HERE, "g11_img_scales.json")) as f:
         c = json.load(f)[cfg_name]
     net = ref_net(160)
