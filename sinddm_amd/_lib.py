@@ -26,6 +26,7 @@ ABI_SYMBOLS = (
 )
 
 
+ABI_VERSION = 3               # SINDDM_ABI_VERSION of include/sinddm_hip.h this binding was written against
 DIM_FP32_CONVS = 0x10000     # SINDDM_DIM_FP32_CONVS of include/sinddm_hip.h: option bit of every `dim` argument
 
 

@@ -38,13 +38,20 @@ def test_header_and_binding_agree():
     hdr = _header_symbols()
     assert hdr, "no declarations parsed"
     assert sorted(_lib.ABI_SYMBOLS) == hdr
+    # one ABI version everywhere: the header's #define, the binding's constant (which __graft_entry__.build() checks the
+    # built library against) and the option bit of `dim`
+    import re
+    txt = open(os.path.join(REPO, "include", "sinddm_hip.h")).read()
+    assert int(re.search(r"#define SINDDM_ABI_VERSION (\d+)", txt).group(1)) == _lib.ABI_VERSION
+    assert int(re.search(r"#define SINDDM_DIM_FP32_CONVS (0x[0-9a-fA-F]+)", txt).group(1), 16) == _lib.DIM_FP32_CONVS
+    assert "_lib.ABI_VERSION" in open(os.path.join(REPO, "__graft_entry__.py")).read()
 
 
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _header_symbols():
         assert hasattr(lib, name), name
-    assert lib.sinddm_abi_version() == 3
+    assert lib.sinddm_abi_version() == _lib.ABI_VERSION == 3
     assert not _lib.missing_symbols()
 
 

@@ -36,7 +36,7 @@ def _diffusion(golden, dim, cfg="C1", **kw):
 def test_library_loaded_and_layout():
     from sinddm_amd import _lib
     lib = _lib.load()
-    assert lib.sinddm_abi_version() == 3
+    assert lib.sinddm_abi_version() == _lib.ABI_VERSION == 3
     assert lib.sinddm_param_count(160) == 1106772
 
 
