@@ -547,13 +547,16 @@ class MultiScaleGaussianDiffusion(nn.Module):
         x_recon = x_recon.detach().requires_grad_(True)
         emb = self.text_embedds_hr if s > 0 else self.text_embedds_lr
         with torch.enable_grad():
-            for _ in range(self.guidance_sub_iters[s]):
+            for i in range(self.guidance_sub_iters[s]):
                 self.clip_model.zero_grad()
                 score = -self.clip_model.calculate_clip_loss((x_recon + 1) * 0.5, emb)
                 clip_grad = torch.autograd.grad(score, x_recon, create_graph=False)[0]
                 if self.clip_mask is None:
                     clip_grad, clip_mask = thresholded_grad(grad=clip_grad, quantile=self.quantile)
                     self.clip_mask = clip_mask.float()
+                if self.save_interm:                                        # models.py:394-404
+                    self._dump_interm(self.clip_mask.to(torch.float64), s, f'clip_mask_s-{s}.png', renorm=False)
+                    self._dump_interm(x_recon.detach().clamp(-1., 1.), s, f'clip_out_s-{s}_t-{t0}_subiter_{i}.png')
                 with torch.no_grad():
                     division_norm = torch.linalg.vector_norm(x_recon * self.clip_mask, dim=(1, 2, 3), keepdim=True) / \
                         torch.linalg.vector_norm(clip_grad * self.clip_mask, dim=(1, 2, 3), keepdim=True)
@@ -571,6 +574,7 @@ class MultiScaleGaussianDiffusion(nn.Module):
         with torch.no_grad():
             eps = self._eps(x, t, int(t[0]), s)
             x_recon, x_t_mix = self.predict_start_from_noise(x, t=t, s=s, noise=eps)
+            self._dump_x_recon(x_recon, int(t[0]), int(s))                  # models.py:360-366
         if self._clip_active(int(t[0]), int(s)):                            # models.py:367-421
             x_recon = self._clip_guidance(x_recon, int(t[0]), int(s), clip_denoised)
         elif self.roi_guided_sampling and (s < self.n_scales - 1):         # models.py:430-431
@@ -686,6 +690,9 @@ class MultiScaleGaussianDiffusion(nn.Module):
         lib = _lib.load()
         x = x.contiguous()
         eps = self._eps(x, None, t, s)
+        if self.save_interm:                                                # models.py:360-366 (x_recon lives inside the fused kernel:
+            tt = torch.full((x.shape[0],), int(t), device=x.device, dtype=torch.long)   # recomputed here, for the dump only)
+            self._dump_x_recon(self.predict_start_from_noise(x, t=tt, s=s, noise=eps)[0], t, s)
         if repeat_noise:
             z = noise_like(x.shape, x.device, True).contiguous()
         else:
@@ -725,15 +732,18 @@ class MultiScaleGaussianDiffusion(nn.Module):
             t_min = 0
         return self._run_steps(img, s, reversed(range(t_min, self.num_timesteps)))
 
-    def _dump_interm(self, img, s, name):
-        """save_interm=True (models.py:469-485,520-546): PNG grid of the running sample after every step (debug aid;
-        the per-step `denoised_t-*` dumps of x_recon are not produced -- x_recon only exists inside the fused kernel)."""
+    def _dump_interm(self, img, s, name, renorm=True):
+        """save_interm=True (models.py:469-485,520-546): PNG grid of the running sample after every step (debug aid)."""
         if not self.save_interm:
             return
         from .trainer import save_image
         folder = Path(str(self.results_folder / f'interm_samples_scale_{s}'))
         folder.mkdir(parents=True, exist_ok=True)
-        save_image((img + 1) * 0.5, str(folder / name), nrow=4)
+        save_image((img + 1) * 0.5 if renorm else img, str(folder / name), nrow=4)
+
+    def _dump_x_recon(self, x_recon, t_host: int, s: int):
+        """save_interm=True: the denoised estimate of the step, `denoised_t-TTT_s-S.png` (models.py:360-366)."""
+        self._dump_interm(x_recon.clamp(-1., 1.), s, f'denoised_t-{int(t_host):03}_s-{int(s)}.png')
 
     @torch.no_grad()
     def sample(self, batch_size=16, scale_0_size=None, s=0):               # models.py:489-499

@@ -42,6 +42,8 @@ def save_image(tensor: torch.Tensor, path: str, nrow: int = 8, padding: int = 2)
     if t.dim() == 3:
         t = t[None]
     t = t.clamp(0, 1)
+    if t.shape[1] == 1:                      # (torchvision's make_grid shows a single-channel image as three equal channels)
+        t = t.repeat(1, 3, 1, 1)
     B, C, H, W = t.shape
     if B == 1:
         # torchvision.utils.make_grid returns a single image as it is: no grid, no 2-pixel frame

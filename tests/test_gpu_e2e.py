@@ -262,17 +262,32 @@ def test_harmonization_mask_blend(golden, tmp_path):
 
 
 def test_save_interm_dumps(golden, tmp_path):
-    """save_interm=True writes the per-step PNG grids of the reference (models.py:469-485,520-546)."""
+    """save_interm=True writes the per-step PNG grids of the reference: the running sample (models.py:469-485,520-546) and the
+    step's denoised estimate x_recon `denoised_t-TTT_s-S.png` (models.py:360-366) -- recomputed from eps for the dump, the
+    step itself still runs the fused kernel; the dumped estimate is checked against the formula of models.py:306-318."""
+    import numpy as np
+    from PIL import Image
     tr, meta = _trainer(golden, tmp_path, T=4)
     d = tr.ema_model
     d.save_interm = True
     d.results_folder = tmp_path / "interm"
+    seen = {}
+    orig = d._dump_x_recon
+    d._dump_x_recon = lambda xr, t, s: (seen.__setitem__((int(s), int(t)), xr.detach().cpu().clone()), orig(xr, t, s))[1]
     x0 = d.sample(batch_size=1)
     d.sample_via_scale(1, x0, s=1, custom_t=2)
     f0 = sorted(os.listdir(tmp_path / "interm" / "interm_samples_scale_0"))
     f1 = sorted(os.listdir(tmp_path / "interm" / "interm_samples_scale_1"))
-    assert f0 == ["input_noise_s-0.png"] + [f"output_t-{i:03}_s-0.png" for i in range(4)]
-    assert f1 == ["noisy_input_s_1.png", "output_t-000_s-1.png", "output_t-001_s-1.png"]
+    assert f0 == sorted(["input_noise_s-0.png"] + [f"output_t-{i:03}_s-0.png" for i in range(4)]
+                        + [f"denoised_t-{i:03}_s-0.png" for i in range(4)])
+    assert f1 == sorted(["noisy_input_s_1.png", "output_t-000_s-1.png", "output_t-001_s-1.png",
+                         "denoised_t-000_s-1.png", "denoised_t-001_s-1.png"])
+    assert set(seen) == {(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1)}
+    # the PNG holds (clamp(x_recon) + 1) / 2 (a single image is saved as it is, like torchvision's make_grid does)
+    xr = seen[(1, 0)]
+    png = np.asarray(Image.open(tmp_path / "interm" / "interm_samples_scale_1" / "denoised_t-000_s-1.png"), dtype=np.float32) / 255
+    want = ((xr.clamp(-1, 1) + 1) * 0.5)[0].permute(1, 2, 0).numpy()
+    assert png.shape == want.shape and np.abs(png - want).max() <= 1.0 / 255 + 1e-6
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):
@@ -441,6 +456,33 @@ def test_clip_guided_p_sample_golden(golden):
         assert float((d.clip_mask.cpu() != torch.from_numpy(g[f"clip_mask_s{s}"])).float().mean()) < 1e-3
         assert rel_l2(d.x_recon_prev.cpu(), g[f"x_recon_prev_s{s}"]) < 2e-5
         assert rel_l2(torch.stack([c.reshape(()) for c in d.clip_score]), g[f"clip_score_s{s}"]) < 1e-5
+
+
+def test_clip_guided_save_interm_dumps(tmp_path):
+    """save_interm=True in the CLIP-guided branch: the reference's `clip_mask_s-S.png` and
+    `clip_out_s-S_t-T_subiter_I.png` (models.py:394-404) next to `denoised_t-TTT_s-S.png` (models.py:360-366); the dumps
+    do not change the samples."""
+    from sinddm_amd.configs import build_diffusion
+    from sinddm_amd.synth import closed_form_tensor, hash_randn, noise_key
+    outs = []
+    for dump in (False, True):
+        net, d = build_diffusion("C1", dim=32, device=torch.device(DEV))
+        d.clip_guided_sampling, d.clip_model = True, _SyntheticScore()
+        d.guidance_sub_iters, d.stop_guidance, d.quantile, d.clip_strength, d.llambda = [2, 0, 0], 0, 0.8, 0.3, 0.2
+        d.save_interm, d.results_folder = dump, tmp_path / "clipdump"
+        H, W = 48, 64
+        d.clip_mask, d.x_recon_prev, d.clip_score = None, None, []
+        d.text_embedds_lr = (closed_form_tensor((2, 3, H, W), phase=2.1, amp=0.3, freq=0.117) + 0.5).to(DEV)
+        d.text_embedds_hr = d.text_embedds_lr
+        d.noise_fn = lambda kind, shape, ss, tt, dev: hash_randn(shape, noise_key("step", ss, tt)).to(dev)
+        x = hash_randn((2, 3, H, W), 91).to(DEV)
+        for t in (5, 4):
+            x = d.p_sample(x, torch.full((2,), t, dtype=torch.long, device=DEV), 0)
+        outs.append(x.cpu())
+    assert torch.equal(outs[0], outs[1])
+    files = sorted(os.listdir(tmp_path / "clipdump" / "interm_samples_scale_0"))
+    assert files == sorted(["clip_mask_s-0.png", "denoised_t-004_s-0.png", "denoised_t-005_s-0.png"]
+                           + [f"clip_out_s-0_t-{t}_subiter_{i}.png" for t in (4, 5) for i in (0, 1)])
 
 
 def test_clip_roi_sampling_golden(golden, tmp_path):
