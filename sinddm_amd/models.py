@@ -132,8 +132,12 @@ class SinDDMNet(nn.Module):
     def __init__(self, dim, out_dim=None, channels=3, with_time_emb=True, multiscale=False, device=None):
         super().__init__()
         if not with_time_emb or not multiscale:
+            # (not a gap against the reference: its forward tests `exists(self.multiscale)` -- true for False as well -- and then
+            # dereferences SinEmbTime / SinEmbScale, which only the multiscale=True, with_time_emb=True constructor creates
+            # (models.py:99-118,136-141): multiscale=False raises AttributeError at the first forward there, with_time_emb=False a TypeError in the constructor -- checked against the reference)
             raise NotImplementedError("the MI355X build implements the configuration main.py uses: "
-                                      "with_time_emb=True, multiscale=True (reference main.py:77-81)")
+                                      "with_time_emb=True, multiscale=True (reference main.py:77-81); the reference's own forward "
+                                      "cannot run any other combination (models.py:136-141)")
         if channels != 3 or default(out_dim, channels) != 3:
             raise NotImplementedError("channels=3 / out_dim=3 only (reference main.py:77-81, models.py:129)")
         self.device = device
