@@ -142,10 +142,10 @@ def _disk(radius: int) -> np.ndarray:
 
 def dilate_mask(mask: torch.Tensor, mode: str) -> np.ndarray:
     """functions.py:21-33 -- binary dilation by a disk (radius 7 harmonization / 20 editing), Gaussian blur
-    (sigma 5), min-max normalisation; returns (1,1,H,W).  The reference calls scikit-image 0.19.3 (absent from this
-    image and from the build container, so this function is NOT pinned by a reference run): restated here on
-    scipy.ndimage with scikit-image's documented defaults (binary_dilation: border value False;
-    filters.gaussian: mode='nearest', truncate=4.0, float64)."""
+    (sigma 5), min-max normalisation; returns (1,1,H,W).  The reference calls scikit-image (pinned 0.19.3; absent from this
+    image's Python): restated on scipy.ndimage with scikit-image's defaults (binary_dilation: border value False;
+    filters.gaussian: mode='nearest', truncate=4.0, float64) and PINNED by fixture G20 = the reference's lines run on
+    scikit-image 0.18.3 itself (tests/golden/make_golden_skimage.py; agreement < 1e-12, tests/test_host.py)."""
     from scipy import ndimage as ndi
     if mode == "harmonization":
         element = _disk(7)
@@ -163,8 +163,8 @@ def dilate_mask(mask: torch.Tensor, mode: str) -> np.ndarray:
 def match_histograms(image: np.ndarray, reference: np.ndarray, channel_axis: int = 2) -> np.ndarray:
     """skimage.exposure.match_histograms (0.19.3) for uint8 HxWxC images, as used by image2image
     (trainer.py:312-314): per channel, map every source level through the reference's inverse CDF
-    (np.interp of the cumulative histograms) and store into the input dtype.  Not pinned by a reference run
-    (scikit-image is absent here); restated from the published algorithm."""
+    (np.interp of the cumulative histograms) and store into the input dtype.  Pinned bit for bit by fixture G20 (scikit-image
+    0.18.3's own output, tests/golden/make_golden_skimage.py)."""
     if image.ndim != reference.ndim or channel_axis != image.ndim - 1:
         raise ValueError("expects HxWxC arrays with the channel axis last")
     if image.shape[-1] != reference.shape[-1]:

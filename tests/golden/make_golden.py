@@ -27,6 +27,7 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
   g18_chain_c3.npz   full C3 chain (6 scales, T=1000, finest 411x512: 2 551 evaluations -- the workload bench.py is quoted on), hash noise
                      (`python tests/golden/make_golden.py g18`, ~10 CPU-minutes)
+  g20_skimage.npz    dilate_mask / match_histograms by scikit-image itself -- written by make_golden_skimage.py under /opt/conda's Python 3.9
   g19_chain_c5_mul24.npz  full C5 chain sampled with scale_mul=(2,4) (92x276 ... 364x1092: 2 521 evaluations), hash noise
                      (`... g19`, ~40 CPU-minutes)
   g16_clip_roi.npz    trainer.clip_roi_sampling (trainer.py:412-468) with the synthetic score: ROI ascent + 5 reverse steps

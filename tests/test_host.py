@@ -224,6 +224,37 @@ def test_match_histograms_properties():
         match_histograms(src, ref[..., :2])
 
 
+def test_g20_scikit_image_helpers_pinned(golden):
+    """G20: `dilate_mask` / `match_histograms` of the reference's image2image path (SinDDM/functions.py:21-33,
+    trainer.py:312-314) computed by scikit-image ITSELF (0.18.3 under /opt/conda's Python 3.9 in the build container; the
+    reference pins 0.19.3, same algorithms: tests/golden/make_golden_skimage.py runs the reference's lines on numpy arrays).
+    sinddm_amd.functions restates them on scipy.ndimage / numpy: histogram matching must agree to the last bit, the blurred
+    masks to rounding (scipy 1.7 there, 1.15 here)."""
+    from sinddm_amd.functions import dilate_mask, match_histograms
+    g = golden("g20_skimage.npz")
+    assert str(g["skimage_version"]).startswith("0.18")
+    n = 0
+    for key in g.files:
+        if not key.startswith("mask_"):
+            continue
+        name = key[len("mask_"):]
+        m = torch.from_numpy(g[key])
+        for mode in ("harmonization", "editing"):
+            want = g[f"dilate_{name}_{mode}"]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                got = dilate_mask(m, mode)
+            assert got.shape == want.shape == (1, 1) + tuple(m.shape[1:]) and got.dtype == np.float64
+            if np.isnan(want).any():                       # the dilated mask covers the image: 0 / 0, in the reference as here
+                assert np.isnan(want).all() and np.isnan(got).all(), (name, mode)
+            else:
+                assert np.abs(got - want).max() < 1e-12, (name, mode, np.abs(got - want).max())
+            n += 1
+    assert n == 8
+    for a, b, o in (("mh_src", "mh_ref", "mh_out"), ("mh_src2", "mh_ref2", "mh_out2"), ("mh_src", "mh_src", "mh_self")):
+        got = match_histograms(image=g[a], reference=g[b], channel_axis=2)
+        assert got.dtype == np.uint8 and np.array_equal(got, g[o]), (o, int(np.abs(got.astype(int) - g[o].astype(int)).max()))
+
+
 def test_dilate_mask_properties():
     from sinddm_amd.functions import dilate_mask
     m = torch.zeros(3, 80, 100)
