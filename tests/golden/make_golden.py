@@ -27,6 +27,7 @@ Fixtures (G-numbers follow SURVEY.md 8(c)):
   g14_chain_c2.npz   full C2 chain (5 scales, T=1000, B=1, dim=160: 2 478 chained evaluations), hash noise
   g18_chain_c3.npz   full C3 chain (6 scales, T=1000, finest 411x512: 2 551 evaluations -- the workload bench.py is quoted on), hash noise
                      (`python tests/golden/make_golden.py g18`, ~10 CPU-minutes)
+  g21_chain_c4.npz   full C4 chain (starry_night, 6 scales, T=1000: 2 693 evaluations), hash noise (`... g21`, ~5 CPU-minutes)
   g20_skimage.npz    dilate_mask / match_histograms by scikit-image itself -- written by make_golden_skimage.py under /opt/conda's Python 3.9
   g19_chain_c5_mul24.npz  full C5 chain sampled with scale_mul=(2,4) (92x276 ... 364x1092: 2 521 evaluations), hash noise
                      (`... g19`, ~40 CPU-minutes)
@@ -792,6 +793,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g18":
         g_chain("C3", "g18_chain_c3.npz")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g21":
+        g_chain("C4", "g21_chain_c4.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "g19":
         g_chain("C5", "g19_chain_c5_mul24.npz", scale_mul=(2, 4))
         return
@@ -821,6 +825,7 @@ def main():
         g17(meta)
         g_chain("C3", "g18_chain_c3.npz")
         g_chain("C5", "g19_chain_c5_mul24.npz", scale_mul=(2, 4))
+        g_chain("C4", "g21_chain_c4.npz")
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
 

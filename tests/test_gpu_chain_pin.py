@@ -139,6 +139,18 @@ def test_full_chain_c5_scale_mul_2_4_batch32_golden(golden):
     assert max(iso) < 1e-4, iso
 
 
+def test_full_chain_c4_t1000_batch128_golden(golden):
+    """G21: C4 (starry_night, 6 scales 49x62 ... 198x252, T = 1000, 2 693 chained evaluations) at its benchmarked global batch
+    of 128 against the REFERENCE's images: the three finest scales run on conv_wh, the coarse ones on the fp32 Winograd kernels.
+    With G9 (C1), G14 (C2), G18 (C3) and G19 (C5) every configuration of BASELINE.json has its full chain pinned."""
+    g = golden("g21_chain_c4.npz")
+    cum, iso = _chain_vs_fixture("C4", g, 128, [8, 8, 8], iso_scales=[3, 5], B_iso=64)
+    print("C4 chain at B=128, rel-L2 per scale (cumulative):", ["%.2e" % e for e in cum])
+    print("C4 chain at B=64, rel-L2 of scales 3 and 5 restarted from the reference's previous scale:", ["%.2e" % e for e in iso])
+    assert max(cum) < 1e-4, cum
+    assert max(iso) < 1e-4, iso
+
+
 def _c1_trainer(tmp_path, golden, dim=160):
     from sinddm_amd.models import MultiScaleGaussianDiffusion, SinDDMNet
     from sinddm_amd.trainer import MultiscaleTrainer

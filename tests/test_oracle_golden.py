@@ -240,6 +240,30 @@ def test_g19_chain_c5_scale_mul_bookkeeping(golden):
         assert np.isfinite(g[f"out_s{s}"]).all()
 
 
+def test_g21_chain_c4_scale1_restart(golden):
+    """G21 (the reference's full C4 chain): bookkeeping of all six scales exactly, and the oracle re-runs scale 1 (65x82, 499 steps)
+    from the reference's scale-0 image onto the reference's scale-1 image."""
+    meta = golden("g11_img_scales.json")
+    g = golden("g21_chain_c4.npz")
+    c4 = meta["C4"]
+    sched = _sched(meta, "C4")
+    assert sched["num_timesteps_ideal"] == list(g["ideal"]) == [1000, 499, 410, 330, 257, 197]
+    assert int(g["plan_len"]) == 1 + sum(sched["num_timesteps_ideal"]) + 5
+    sizes = [tuple(s) for s in c4["image_sizes_hw"]]
+    for i, hw in enumerate(sizes):
+        assert g[f"out_s{i}"].shape == (1, 3) + hw
+    sd = closed_form_state_dict(160)
+    s = 1
+    with torch.no_grad():
+        up = O.bilinear_upsample(torch.from_numpy(g["out_s0"]), sizes[s])
+        total_t = sched["num_timesteps_ideal"][s]
+        x = O.q_sample(sched, up, torch.full((1,), total_t, dtype=torch.long),
+                       hash_randn((1, 3) + sizes[s], noise_key("renoise", s, 0)))
+        for t in range(total_t - 1, -1, -1):
+            x = O.p_sample(sched, sd, x, t, s, hash_randn((1, 3) + sizes[s], noise_key("step", s, t)), up)
+    assert rel_l2(x, g["out_s1"]) < 1e-5
+
+
 def test_adam_and_lr_restatement():
     torch.manual_seed(0)
     p = torch.randn(50)
