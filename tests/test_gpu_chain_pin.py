@@ -124,7 +124,7 @@ def test_full_chain_c3_t1000_batch64_golden(golden):
     assert max(iso) < 1e-4, iso
 
 
-def test_full_chain_c5_scale_mul_2_4_batch32_golden(golden):
+def test_full_chain_c5_scale_mul_2_4_golden(golden):
     """G19: C5 (marinabaysands, 5 scales, T = 1000) sampled with --scale_mul 2 4 -- the odd geometry 92x276 ... 364x1092 of
     reference trainer.py:247-252 / models.py:549-568 (int() truncation of the stretched sizes, bilinear upsample between
     stretched scales) -- at batch 16 (its benchmarked global batch is 32; 16 already puts every scale on conv_wh and halves the
